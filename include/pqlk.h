@@ -1,0 +1,236 @@
+/*
+ * pqlk.h -- C ABI of libpqlk.so, the MI355X (gfx950) kernel library for the
+ * Parallel-Q-Learning learner hot path.
+ *
+ * The reference (supersglzc/pql) is pure Python on PyTorch: it has no FFI.  Its
+ * plugin boundary is (i) class-name lookup of models/algos, (ii) the Python
+ * signatures of the replay/learner objects and (iii) the Hydra key set
+ * (SURVEY.md section 8b).  pql_amd/ keeps (i)-(iii) and calls the entry points below
+ * through ctypes; every entry point names the reference code it replaces
+ * (path:line under the reference tree).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / HIP types in signatures
+ *     (pqlk_stream_t is a hipStream_t passed as void*; NULL = default stream).
+ *   - All pointers are DEVICE pointers on the current HIP device unless a
+ *     parameter is documented as host.  The caller owns every buffer; the
+ *     library never allocates, frees or retains a pointer past the call.
+ *   - Every call is asynchronous on the given stream and performs no host
+ *     synchronisation, so calls can be captured into a hipGraph.
+ *   - Return value: 0 = OK; >0 = PQLK_E_* argument error; <0 = -(hipError_t).
+ *     pqlk_strerror() describes either.
+ *   - Matrices are row-major fp32 with a leading dimension ("ld", in floats)
+ *     that is a multiple of 32 (pqlk_ld()); pad columns must be zero on input
+ *     and are written as zero on output.
+ */
+#ifndef PQLK_H
+#define PQLK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pqlk_stream_t;
+
+#define PQLK_VERSION 100 /* 0.1.0 */
+
+enum {
+  PQLK_OK = 0,
+  PQLK_E_NULL = 1,     /* required pointer is NULL */
+  PQLK_E_SHAPE = 2,    /* dimension <= 0 or inconsistent */
+  PQLK_E_RANGE = 3,    /* index / pointer argument out of range */
+  PQLK_E_ALIGN = 4,    /* leading dimension not a multiple of 32 / pointer not 16-B aligned */
+  PQLK_E_UNSUPPORTED = 5,
+  PQLK_E_WORKSPACE = 6 /* workspace too small */
+};
+
+int pqlk_version(void);
+const char* pqlk_strerror(int rc);
+
+/* Leading dimension used for a matrix with `cols` logical columns: round up to 32 floats (128 B). */
+int64_t pqlk_ld(int64_t cols);
+
+/* ------------------------------------------------------------------------------------------------
+ * Replay ring  (reference: pql/replay/simple_replay.py:4-104, pql/algo/pql_p_learner.py:32-37,49-50,66-85)
+ *
+ * Storage is one array of fixed-stride records instead of the reference's five SoA tensors:
+ *     record = [ obs(O) pad4 | next_obs(O) pad4 | action(A) pad4 | reward, done(0.0/1.0), 0, 0 | zero pad ]
+ * (each field starts on a 16-B boundary so records move with dwordx4 accesses for any O, A).
+ * rec_ld = pqlk_replay_rec_ld(O, A) floats (multiple of 32 => every record starts on a 128-B line, so
+ * a random sample touches ceil(rec_bytes/128) HBM lines instead of ~10 for the SoA layout).
+ * The obs-only ring of the P-learner is the same thing with A = -1 (record = obs, rec_ld = pqlk_ld(O)).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  float* records;    /* (capacity, rec_ld) */
+  int64_t capacity;  /* rows */
+  int32_t obs_dim;   /* O */
+  int32_t act_dim;   /* A, or -1 for an obs-only ring */
+  int32_t rec_ld;    /* floats per record */
+  int32_t reserved;
+} PqlReplayDesc;
+
+int64_t pqlk_replay_rec_ld(int32_t obs_dim, int32_t act_dim);
+
+/* Ring insert of m rows at row `next_p` (host-side pointer law stays in Python, it is integer
+ * bookkeeping: simple_replay.py:52-83).  Row r of the source goes to (dst_start + r) for r in
+ * [0, m); the caller issues one call per contiguous segment (head, then wrapped tail).
+ * done is canonicalised to 0.0/1.0 (reference: `.bool()` on ingest :51, `.float()` on sample :103).
+ * act/rew/next_obs/done are ignored (may be NULL) for an obs-only ring.
+ * src_ld_* are the source row strides in floats (contiguous tensors: O, A, 1, O, 1). */
+int pqlk_replay_insert(const PqlReplayDesc* ring, int64_t dst_start, int64_t m,
+                       const float* obs, int64_t ld_obs, const float* act, int64_t ld_act,
+                       const float* rew, int64_t ld_rew, const float* next_obs, int64_t ld_nobs,
+                       const float* done, int64_t ld_done, pqlk_stream_t stream);
+
+/* Plain sample gather = ReplayBuffer.sample_batch with the index vector supplied
+ * (simple_replay.py:98-104): five contiguous outputs (B,O),(B,A),(B,1),(B,O),(B,1) fp32. */
+int pqlk_replay_gather(const PqlReplayDesc* ring, const int64_t* idx, int64_t b,
+                       float* obs, float* act, float* rew, float* next_obs, float* done,
+                       pqlk_stream_t stream);
+
+/* Fused learner gather: sample + normalize (pql/utils/common.py:139-145:
+ * clamp((x-mean)/sqrt(var+eps), -5, 5); mean == NULL => identity; clamp5 = 0 => no clamp, the DDPG
+ * flavour ddpg.py:124-126) + torch.cat((obs, action)) (pql/models/mlp.py:197) in one pass.
+ *   x_sa   (B, ld_sa)  : [ norm(obs) | action | 0 ]          critic input            (may be NULL)
+ *   xn_sa  (B, ld_sa)  : [ norm(next_obs) | untouched | 0 ]  target-critic input; the action columns
+ *                        are filled later by the target actor                        (may be NULL)
+ *   xn_obs (B, ld_o)   : [ norm(next_obs) | 0 ]              target-actor input      (may be NULL)
+ *   rew, done (B)                                                                    (may be NULL)
+ * For an obs-only ring only x_sa (obs columns + zeroed action columns) and/or xn_obs (= norm(obs)
+ * with ld_o) are written (pql_p_learner.py:49-52). */
+int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t* idx, int64_t b,
+                             const float* mean, const float* var, float eps, int clamp5,
+                             float* x_sa, int64_t ld_sa, float* xn_sa, float* xn_obs, int64_t ld_o,
+                             float* rew, float* done, pqlk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * n-step assembler  (reference: pql/replay/nstep_replay.py:6-92)
+ *
+ * Circular per-env window instead of the reference's five torch.cat FIFO shifts per step.
+ * window: (N, nstep, win_ld) fp32, win_ld = pqlk_replay_rec_ld(O, A), same record layout as the ring.
+ * `count` = number of steps pushed before this call (host integer; slot of step s is s % nstep).
+ * Inputs are the (N, T, .) slabs of PQLActor.explore_env (pql_actor.py:89-93,117-121).
+ * Emits, for every step s = count + t with s + 1 >= nstep, one row per env in TIME-MAJOR order
+ * (row = (s - first_emit_step) * N + env; nstep_replay.py:65), to five contiguous outputs.
+ * gamma_pow: nstep floats (host pointer), gamma^j computed in double, rounded to fp32 (:24).
+ * Reward sum order is torch's row-sum order for n <= 5 (see oracle NStepRef._emit).
+ * Returns the number of emitted rows through *rows_out (host pointer, may be NULL). */
+int pqlk_nstep_push_emit(float* window, int64_t num_envs, int32_t nstep, int32_t obs_dim, int32_t act_dim,
+                         int64_t count, int64_t t_steps,
+                         const float* obs, const float* act, const float* rew, const float* next_obs,
+                         const float* done, const float* gamma_pow /*host*/,
+                         float* o_obs, float* o_act, float* o_rew, float* o_next_obs, float* o_done,
+                         int64_t* rows_out /*host*/, pqlk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * MLP family  (reference: pql/models/mlp.py:15-40 MLPNet, :177-179 TanhMLPPolicy, :186-203 DoubleQ,
+ * :244-267 DistributionalDoubleQ; backward = torch autograd of the same)
+ *
+ * One descriptor covers `n_nets` structurally identical nets evaluated on a shared input
+ * (1 = actor, 2 = twin critic).  Parameters live in ONE flat fp32 arena:
+ *   for net in 0..n_nets-1: for layer in 0..n_layers-1:
+ *       W  (out_l, pqlk_ld(in_l))  row-major, y = x W^T + b  (same (out,in) orientation as nn.Linear)
+ *       b  (pqlk_ld(out_l))
+ * Gradients, Adam moments and Polyak targets use the same layout, so the optimiser is one pass over
+ * the arena.  Hidden activation is ELU(alpha=1).
+ * ---------------------------------------------------------------------------------------------- */
+#define PQLK_MAX_LAYERS 8
+
+enum { PQLK_ACT_NONE = 0, PQLK_ACT_TANH = 1, PQLK_ACT_TANH_NOISE = 2 };
+
+typedef struct {
+  int32_t n_layers;                 /* number of Linear layers (hidden + 1) */
+  int32_t n_nets;                   /* 1 or 2 */
+  int32_t dims[PQLK_MAX_LAYERS + 1]; /* in, h1, ..., out */
+} PqlMlpDesc;
+
+int64_t pqlk_mlp_param_floats(const PqlMlpDesc* d);                       /* arena size, all nets */
+int64_t pqlk_mlp_net_stride(const PqlMlpDesc* d);                         /* floats between nets */
+int pqlk_mlp_layer_offsets(const PqlMlpDesc* d, int32_t layer, int64_t* w_off, int64_t* b_off); /* within a net */
+int64_t pqlk_mlp_acts_floats(const PqlMlpDesc* d, int64_t b);             /* activation stash, all nets */
+int pqlk_mlp_act_offset(const PqlMlpDesc* d, int64_t b, int32_t net, int32_t layer, int64_t* off, int64_t* ld);
+int64_t pqlk_mlp_bwd_ws_floats(const PqlMlpDesc* d, int64_t b, int32_t splits); /* backward workspace */
+
+/* Forward.  x: (B, ldx) with ldx >= pqlk_ld(dims[0]).  acts: stash of every layer's post-activation
+ * output (layer l of net n at pqlk_mlp_act_offset).  The last layer's output gets `out_act`:
+ *   NONE       : logits / Q values
+ *   TANH       : TanhMLPPolicy (mlp.py:179)
+ *   TANH_NOISE : tanh, then target-policy smoothing a' = clamp(a + clamp(noise_std*draw, +-noise_clip), +-1)
+ *                (pql/utils/noise.py:19-27 via pql_v_learner.py:63-71); draw: (B, dims[L]) contiguous N(0,1).
+ * If out2 != NULL (n_nets must be 1) the final output is ALSO written to out2 with row stride ld_out2
+ * (used to drop the actor's action into the action columns of a critic input: torch.cat for free). */
+int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                     int32_t out_act, const float* draw, float noise_std, float noise_clip,
+                     float* acts, float* out2, int64_t ld_out2, pqlk_stream_t stream);
+
+/* Backward.  dy: (n_nets, B, pqlk_ld(out)) gradient w.r.t. the last layer's PRE-activation output
+ * (loss kernels below produce exactly that).  grads (arena layout) is overwritten with the full
+ * parameter gradient when != NULL (deterministic split-batch partial sums through `ws`).
+ * dx (B, ld_dx) receives the input gradient summed over nets when != NULL; if dx_tanh_of != NULL the
+ * columns [dx_col0, dx_col0 + dx_cols) are multiplied by (1 - a^2) with a = dx_tanh_of (B, ld_tanh)
+ * and ONLY those columns are written, compacted to column 0 of dx (DPG chain through the actor's
+ * tanh, pql_p_learner.py:55-58). */
+int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                      const float* acts, const float* dy, float* grads, int32_t splits,
+                      float* dx, int64_t ld_dx, int32_t dx_col0, int32_t dx_cols,
+                      const float* dx_tanh_of, int64_t ld_tanh,
+                      float* ws, int64_t ws_floats, pqlk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Losses.  Each writes dy (2, B, ld) for pqlk_mlp_backward and one scalar loss into loss_out[0]
+ * (device), via per-block partials in `scratch` (>= 1024 floats) reduced in fixed order.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* TD target + twin MSE (pql_v_learner.py:104-108): y = r + (1-d) * gamma_n * min(qt1, qt2);
+ * loss = mean((q1-y)^2) + mean((q2-y)^2).  q, qt: (2, B, ld) with the value in column 0. */
+int pqlk_td_mse_loss(const float* q, const float* qt, int64_t ld, const float* rew, const float* done,
+                     float gamma_n, int64_t b, float* dy, float* loss_out, float* scratch, pqlk_stream_t stream);
+
+/* C51: softmax of target logits, categorical projection x2 (pql/utils/distl_util.py:4-20), elementwise
+ * min (pql_v_learner.py:83-102), softmax of current logits, twin BCE (mean over B*K, log clamped at
+ * -100 like torch) and its gradient w.r.t. the current logits.  logits: (2, B, ld), K <= 64 atoms;
+ * support = DistributionalDoubleQ.z_atoms (mlp.py:253), passed in so its fp32 values are torch.linspace's.
+ * If proj_out != NULL the (B, K) target pmf is also stored (tests). */
+int pqlk_c51_bce_loss(const float* logits, const float* logits_t, int64_t ld, int32_t k,
+                      const float* rew, const float* done, const float* support /*(K) z atoms*/, float gamma_n,
+                      float v_min, float v_max, int64_t b, float* dy, float* loss_out, float* proj_out,
+                      float* scratch, pqlk_stream_t stream);
+
+/* Stand-alone projection = projection() of distl_util.py:4-20 on a given pmf (B, K) contiguous. */
+int pqlk_c51_project(const float* p, const float* rew, const float* done, const float* support, float gamma_n,
+                     float v_min, float v_max, int32_t k, int64_t b, float* out, pqlk_stream_t stream);
+
+/* DPG actor loss (pql_p_learner.py:56-57): L = -mean(min(Q1,Q2)); dy = dL/dQ (ties split evenly, as
+ * torch.min's backward).  k == 1: q (2,B,ld) scalar heads.  k > 1: logits of the distributional critic,
+ * Q_i = sum softmax(logits_i) * z (mlp.py:256-260), dy = gradient w.r.t. the logits. */
+int pqlk_dpg_loss(const float* q, int64_t ld, int32_t k, const float* support /*(K), NULL when k == 1*/, int64_t b,
+                  float* dy, float* loss_out, float* scratch, pqlk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimiser: clip_grad_norm_ + AdamW (+ Polyak) over flat arenas
+ * (pql_v_learner.py:124-133, pql_p_learner.py:87-96, pql/utils/torch_util.py:9-12).
+ *   total = ||g||_2 ; g *= min(1, max_norm / (total + 1e-6))   (max_norm <= 0 disables clipping)
+ *   p *= 1 - lr*wd ; m += (g-m)(1-b1) ; v = b2 v + (1-b2) g^2
+ *   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ *   target = p*tau + target*(1-tau)                              (target may be NULL)
+ * step_dev: device int32 counter t, incremented by the call (graph-replay safe).
+ * scratch: >= 2048 floats.  gnorm_out (device, may be NULL) receives the pre-clip norm.
+ * ---------------------------------------------------------------------------------------------- */
+int pqlk_clip_adamw_polyak(float* p, float* g, float* m, float* v, float* target, int64_t n,
+                           float max_norm, float lr, float b1, float b2, float eps, float wd, float tau,
+                           int32_t* step_dev, float* gnorm_out, float* scratch, pqlk_stream_t stream);
+
+/* soft_update alone (torch_util.py:9-12): target = cur*tau + target*(1-tau). */
+int pqlk_polyak(float* target, const float* cur, int64_t n, float tau, pqlk_stream_t stream);
+
+/* RunningMeanStd.update batch moments (torch_util.py:77-81): mean and UNBIASED variance over rows of
+ * x (N, ldx) for `cols` columns -> mean_out, var_out (cols).  The Chan merge (:87-103) stays on host. */
+int pqlk_batch_moments(const float* x, int64_t ldx, int64_t n, int32_t cols, float* mean_out, float* var_out,
+                       pqlk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQLK_H */

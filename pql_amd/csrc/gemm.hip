@@ -1,0 +1,579 @@
+// fp32 MFMA GEMMs for the MLP family and the per-MLP forward/backward drivers.
+//
+// Reference arithmetic: nn.Linear / ELU / tanh chains of pql/models/mlp.py:15-40,177-203,244-267 and
+// their autograd.  All three products run on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma chain,
+// 256 FLOP/clk/CU = the 157 TFLOP/s fp32 roof of gfx950):
+//   FWD  Y[m,n]  = act( sum_k X[m,k] W[n,k] + b[n] )                 (X, W both k-contiguous)
+//   DX   dX[m,k] = ( sum_g sum_n dY_g[m,n] W_g[n,k] ) * act'(H[m,k])  (dY k-contiguous, W reduction-row)
+//   DW   dW[n,k] = sum_{m in split} dY[m,n] X[m,k] ; db[n] = sum_m dY[m,n]   (both reduction-row)
+// Block = 256 threads = 2x2 waves, each wave a (BM/2)x(BN/2) patch of 32x32 MFMA tiles; reduction is
+// walked in 32-wide steps through double-buffered LDS with register prefetch (one barrier per step).
+//
+// MFMA operand maps (cdna_hip_programming.md section 3): lane l = (r = l&31, h = l>>5):
+//   A operand = A[i=r][k=h], B operand = B[k=h][j=r]; D: col = r, row = (reg&3) + 8*(reg>>2) + 4*h.
+// A 32-wide reduction step is consumed as 4 groups (k8) x 4 MFMAs (t); lane half h supplies reduction
+// index kk = 8*k8 + 4*h + t.  A and B use the same map, so any such bijection is a valid dot product;
+// this one lets k-contiguous operands be fetched with one ds_read_b128 per four MFMAs.
+#include "pqlk_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { MODE_FWD = 0, MODE_DX = 1, MODE_DW = 2 };
+enum { EPI_NONE = 0, EPI_ELU = 1, EPI_TANH = 2, EPI_TANH_NOISE = 3, EPI_DELU = 4, EPI_DTANH_SLICE = 5 };
+
+struct GemmP {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;  // FWD: bias (per group); DW: unused
+  const float* aux;   // FWD/TANH_NOISE: draw (M, N) contiguous; DX/DELU: H (M, ldaux); DX/DTANH: a (M, ldaux)
+  float* C2;          // FWD: optional second destination of the final output (group 0 only)
+  float* dbias;       // DW: bias-gradient slab (per group/split)
+  int M, N, K;        // C is M x N; reduction length K (FWD: padded in-features; DX: out-features; DW: batch)
+  int lda, ldb, ldc, ldaux, ldc2;
+  int ncols_store;    // FWD/DX: columns [N, ncols_store) are written as zero (pad); DW: = N
+  long long sA, sB, sC, sBias, sAux;  // per-group strides (floats)
+  int groups;         // DX with zsum: groups summed inside the block; otherwise grid.z = groups
+  int zsum;
+  int splits;         // DW: grid.z = groups*splits, split s covers rows [s*rows_per_split, ...)
+  int rows_per_split;
+  long long sSplit;   // DW: floats between split slabs (C and dbias)
+  int epi;
+  int col0, ncol;     // DX/DTANH_SLICE: only columns [col0, col0+ncol) are written, compacted to column 0
+  int n_base;         // first output column covered by the grid (multiple of 4)
+  float noise_std, noise_clip;
+};
+
+#define KT 32       // reduction elements per LDS stage
+#define KC_LD 36    // row stride of a k-contiguous tile (32 + 4: odd multiple of 4 -> conflict-free b128 reads)
+
+// ---- tile loaders: global -> registers -> LDS -------------------------------------------------
+// k-contiguous tile: ROWS rows x 32 floats.  Chunk c (16 B): row = c>>3, kc = c&7.
+template <int ROWS>
+struct KcTile {
+  static constexpr int CH = ROWS * 8 / 256;  // float4 chunks per thread
+  float4 v[CH];
+  __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int row_lim, int k0, int k_lim,
+                                       int tid) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = tid + 256 * i;
+      const int row = row0 + (c >> 3);
+      const int k = k0 + ((c & 7) << 2);
+      if (row < row_lim && k < k_lim)
+        v[i] = *reinterpret_cast<const float4*>(base + (long long)row * ld + k);
+      else
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = tid + 256 * i;
+      *reinterpret_cast<float4*>(lds + (c >> 3) * KC_LD + ((c & 7) << 2)) = v[i];
+    }
+  }
+};
+
+// reduction-row tile: 32 rows x COLS floats, row stride COLS+4.  Chunk c: row = c / (COLS/4), cc = c % (COLS/4).
+template <int COLS>
+struct RrTile {
+  static constexpr int CPR = COLS / 4;
+  static constexpr int CH = 32 * CPR / 256;
+  static constexpr int LD = COLS + 4;
+  float4 v[CH];
+  __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int row_lim, int col0, int col_lim,
+                                       int tid) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = tid + 256 * i;
+      const int row = row0 + c / CPR;
+      const int col = col0 + ((c % CPR) << 2);
+      if (row < row_lim && col < col_lim)
+        v[i] = *reinterpret_cast<const float4*>(base + (long long)row * ld + col);
+      else
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = tid + 256 * i;
+      *reinterpret_cast<float4*>(lds + (c / CPR) * LD + ((c % CPR) << 2)) = v[i];
+    }
+  }
+};
+
+template <int MODE, int BM, int BN>
+struct Smem {
+  static constexpr int A_FLOATS = (MODE == MODE_DW) ? 32 * (BM + 4) : BM * KC_LD;
+  static constexpr int B_FLOATS = (MODE == MODE_FWD) ? BN * KC_LD : 32 * (BN + 4);
+  static constexpr int STAGE = A_FLOATS + B_FLOATS;
+};
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+
+template <int MODE, int BM, int BN>
+__global__ __launch_bounds__(256) void k_gemm(GemmP p) {
+  constexpr int WM = BM / 2, WN = BN / 2;  // per-wave patch
+  constexpr int MI = WM / 32, NJ = WN / 32;
+  using S = Smem<MODE, BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
+  const int m0 = blockIdx.y * BM, n0 = p.n_base + blockIdx.x * BN;
+
+  int g0 = 0, g1 = 1, split = 0;
+  if (MODE == MODE_DW) {
+    g0 = blockIdx.z / p.splits;
+    split = blockIdx.z % p.splits;
+    g1 = g0 + 1;
+  } else if (MODE == MODE_DX && p.zsum) {
+    g0 = 0;
+    g1 = p.groups;
+  } else {
+    g0 = blockIdx.z;
+    g1 = g0 + 1;
+  }
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  float dbacc = 0.f;  // DW: column sum of dY for row tid of this block's dW tile (blockIdx.x == 0 only)
+
+  for (int g = g0; g < g1; ++g) {
+    const float* A = p.A + (long long)g * p.sA;
+    const float* B = p.B + (long long)g * p.sB;
+    // reduction range
+    int kbeg = 0, kend = p.K;
+    if (MODE == MODE_DW) {
+      kbeg = split * p.rows_per_split;
+      kend = min(p.K, kbeg + p.rows_per_split);
+    }
+    const int nk = (kend - kbeg + KT - 1) / KT;
+    if (nk <= 0) continue;
+
+    // register prefetch buffers
+    KcTile<BM> a_kc;
+    RrTile<BM> a_rr;
+    KcTile<BN> b_kc;
+    RrTile<BN> b_rr;
+
+    auto gload = [&](int kt) {
+      const int k0 = kbeg + kt * KT;
+      if (MODE == MODE_FWD) {
+        a_kc.load(A, p.lda, m0, p.M, k0, kend, tid);
+        b_kc.load(B, p.ldb, n0, p.N, k0, kend, tid);
+      } else if (MODE == MODE_DX) {
+        a_kc.load(A, p.lda, m0, p.M, k0, p.lda, tid);   // dY pad columns are zero
+        b_rr.load(B, p.ldb, k0, kend, n0, p.ldb, tid);  // W rows n (reduction), cols = in-features (padded ld)
+      } else {
+        a_rr.load(A, p.lda, k0, kend, m0, p.lda, tid);  // dY rows m (reduction), cols = dW rows
+        b_rr.load(B, p.ldb, k0, kend, n0, p.ldb, tid);  // X rows m, cols = dW cols
+      }
+    };
+    auto sstore = [&](int stage) {
+      float* sa = smem + stage * S::STAGE;
+      float* sb = sa + S::A_FLOATS;
+      if (MODE == MODE_FWD) {
+        a_kc.store(sa, tid);
+        b_kc.store(sb, tid);
+      } else if (MODE == MODE_DX) {
+        a_kc.store(sa, tid);
+        b_rr.store(sb, tid);
+      } else {
+        a_rr.store(sa, tid);
+        b_rr.store(sb, tid);
+      }
+    };
+
+    gload(0);
+    __syncthreads();  // previous group's last stage may still be in use
+    sstore(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int stage = kt & 1;
+      if (kt + 1 < nk) gload(kt + 1);
+      const float* sa = smem + stage * S::STAGE;
+      const float* sb = sa + S::A_FLOATS;
+
+      if (MODE == MODE_DW && blockIdx.x == 0 && tid < BM) {
+#pragma unroll 8
+        for (int rr = 0; rr < 32; ++rr) dbacc += sa[rr * (BM + 4) + tid];
+      }
+
+#pragma unroll
+      for (int k8 = 0; k8 < 4; ++k8) {
+        float af[MI][4], bf[NJ][4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if (MODE == MODE_DW) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) af[i][t] = sa[(8 * k8 + 4 * h + t) * (BM + 4) + wm + 32 * i + r];
+          } else {
+            const float4 v = *reinterpret_cast<const float4*>(sa + (wm + 32 * i + r) * KC_LD + 8 * k8 + 4 * h);
+            af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (MODE == MODE_FWD) {
+            const float4 v = *reinterpret_cast<const float4*>(sb + (wn + 32 * j + r) * KC_LD + 8 * k8 + 4 * h);
+            bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bf[j][t] = sb[(8 * k8 + 4 * h + t) * (BN + 4) + wn + 32 * j + r];
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+      }
+
+      if (kt + 1 < nk) sstore(stage ^ 1);
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------------------------ epilogue
+  if (MODE == MODE_DW) {
+    float* C = p.C + (long long)g0 * p.sC + (long long)split * p.sSplit;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int col = n0 + wn + 32 * j + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (row < p.M && col < p.N) C[(long long)row * p.ldc + col] = acc[i][j][e];
+        }
+      }
+    if (blockIdx.x == 0 && tid < BM && p.dbias) {
+      float* db = p.dbias + (long long)g0 * p.sBias + (long long)split * p.sSplit;
+      const int row = m0 + tid;
+      if (row < p.ncols_store) db[row] = row < p.M ? dbacc : 0.f;  // ncols_store = pqlk_ld(out): zero bias pad
+    }
+    return;
+  }
+
+  const int g = (MODE == MODE_DX && p.zsum) ? 0 : g0;
+  float* C = p.C + (long long)g * p.sC;
+  const float* bias = (MODE == MODE_FWD && p.bias) ? p.bias + (long long)g * p.sBias : nullptr;
+  const float* aux = p.aux ? p.aux + (long long)g * p.sAux : nullptr;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + wn + 32 * j + r;
+      const float bv = (bias && col < p.N) ? bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (row >= p.M) continue;
+        float v = acc[i][j][e];
+        if (MODE == MODE_FWD) {
+          if (col >= p.ncols_store) continue;
+          if (col < p.N) {
+            v += bv;
+            if (p.epi == EPI_ELU) v = elu1(v);
+            else if (p.epi == EPI_TANH) v = tanhf(v);
+            else if (p.epi == EPI_TANH_NOISE) {
+              v = tanhf(v);
+              float nz = p.noise_std * aux[(long long)row * p.N + col];
+              nz = fminf(fmaxf(nz, -p.noise_clip), p.noise_clip);
+              v = fminf(fmaxf(v + nz, -1.f), 1.f);
+            }
+          } else {
+            v = 0.f;
+          }
+          C[(long long)row * p.ldc + col] = v;
+          if (p.C2 && g == 0 && col < p.N) p.C2[(long long)row * p.ldc2 + col] = v;
+        } else {  // MODE_DX
+          if (p.epi == EPI_DTANH_SLICE) {
+            const int cc = col - p.col0;
+            if (cc < 0 || cc >= p.ncol) continue;
+            const float a = aux[(long long)row * p.ldaux + cc];
+            C[(long long)row * p.ldc + cc] = v * (1.f - a * a);
+          } else {
+            if (col >= p.ncols_store) continue;
+            if (col < p.N) {
+              if (p.epi == EPI_DELU) {
+                const float hval = aux[(long long)row * p.ldaux + col];
+                v = hval > 0.f ? v : v * (hval + 1.f);  // ELU'(x) = exp(x) = elu(x) + 1 for x <= 0
+              }
+            } else {
+              v = 0.f;
+            }
+            C[(long long)row * p.ldc + col] = v;
+          }
+        }
+      }
+    }
+}
+
+template <int MODE, int BM, int BN>
+static int launch_gemm(GemmP p, int gz, hipStream_t st) {
+  using S = Smem<MODE, BM, BN>;
+  const size_t shmem = (size_t)2 * S::STAGE * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, BM, BN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return -(int)e;
+    attr_set = true;
+  }
+  int ncols = (MODE == MODE_DW) ? p.N : p.ncols_store;
+  p.n_base = 0;
+  if (MODE == MODE_DX && p.epi == EPI_DTANH_SLICE) {  // only the action columns are wanted
+    p.n_base = p.col0 & ~3;
+    ncols = p.col0 + p.ncol - p.n_base;
+  }
+  dim3 grid((unsigned)((ncols + BN - 1) / BN), (unsigned)((p.M + BM - 1) / BM), (unsigned)gz);
+  hipLaunchKernelGGL((k_gemm<MODE, BM, BN>), grid, dim3(256), shmem, st, p);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}
+
+// Pick the tile: 128x128 when that already gives every CU a block, else 64x64.
+template <int MODE>
+static int launch_auto(const GemmP& p, int gz, hipStream_t st) {
+  const int ncols = (MODE == MODE_DW) ? p.N : p.ncols_store;
+  const long long big = (long long)((p.M + 127) / 128) * ((ncols + 127) / 128) * gz;
+  if (big >= 256 && ncols >= 128) return launch_gemm<MODE, 128, 128>(p, gz, st);
+  return launch_gemm<MODE, 64, 64>(p, gz, st);
+}
+
+// ================================================================================================
+// descriptor helpers
+static int desc_ok(const PqlMlpDesc* d) {
+  if (!d) return PQLK_E_NULL;
+  if (d->n_layers < 1 || d->n_layers > PQLK_MAX_LAYERS) return PQLK_E_SHAPE;
+  if (d->n_nets < 1 || d->n_nets > 2) return PQLK_E_UNSUPPORTED;
+  for (int i = 0; i <= d->n_layers; ++i)
+    if (d->dims[i] <= 0) return PQLK_E_SHAPE;
+  return PQLK_OK;
+}
+
+extern "C" int64_t pqlk_mlp_net_stride(const PqlMlpDesc* d) {
+  if (desc_ok(d)) return 0;
+  int64_t n = 0;
+  for (int l = 0; l < d->n_layers; ++l) n += (int64_t)d->dims[l + 1] * pqlk_ld(d->dims[l]) + pqlk_ld(d->dims[l + 1]);
+  return n;
+}
+extern "C" int64_t pqlk_mlp_param_floats(const PqlMlpDesc* d) { return pqlk_mlp_net_stride(d) * (d ? d->n_nets : 0); }
+
+extern "C" int pqlk_mlp_layer_offsets(const PqlMlpDesc* d, int32_t layer, int64_t* w_off, int64_t* b_off) {
+  int rc = desc_ok(d);
+  if (rc) return rc;
+  PQLK_REQUIRE(layer >= 0 && layer < d->n_layers, PQLK_E_RANGE);
+  int64_t n = 0;
+  for (int l = 0; l < layer; ++l) n += (int64_t)d->dims[l + 1] * pqlk_ld(d->dims[l]) + pqlk_ld(d->dims[l + 1]);
+  if (w_off) *w_off = n;
+  if (b_off) *b_off = n + (int64_t)d->dims[layer + 1] * pqlk_ld(d->dims[layer]);
+  return PQLK_OK;
+}
+
+extern "C" int64_t pqlk_mlp_acts_floats(const PqlMlpDesc* d, int64_t b) {
+  if (desc_ok(d) || b <= 0) return 0;
+  int64_t n = 0;
+  for (int l = 0; l < d->n_layers; ++l) n += (int64_t)d->n_nets * b * pqlk_ld(d->dims[l + 1]);
+  return n;
+}
+
+extern "C" int pqlk_mlp_act_offset(const PqlMlpDesc* d, int64_t b, int32_t net, int32_t layer, int64_t* off, int64_t* ld) {
+  int rc = desc_ok(d);
+  if (rc) return rc;
+  PQLK_REQUIRE(layer >= 0 && layer < d->n_layers && net >= 0 && net < d->n_nets && b > 0, PQLK_E_RANGE);
+  int64_t n = 0;
+  for (int l = 0; l < layer; ++l) n += (int64_t)d->n_nets * b * pqlk_ld(d->dims[l + 1]);
+  n += (int64_t)net * b * pqlk_ld(d->dims[layer + 1]);
+  if (off) *off = n;
+  if (ld) *ld = pqlk_ld(d->dims[layer + 1]);
+  return PQLK_OK;
+}
+
+static int64_t max_hidden_ld(const PqlMlpDesc* d) {
+  int64_t m = 0;
+  for (int l = 1; l <= d->n_layers; ++l) m = pqlk_ld(d->dims[l]) > m ? pqlk_ld(d->dims[l]) : m;
+  return m;
+}
+
+extern "C" int64_t pqlk_mlp_bwd_ws_floats(const PqlMlpDesc* d, int64_t b, int32_t splits) {
+  if (desc_ok(d) || b <= 0 || splits < 1) return 0;
+  return 2 * (int64_t)d->n_nets * b * max_hidden_ld(d) + (int64_t)splits * pqlk_mlp_param_floats(d);
+}
+
+// ================================================================================================
+extern "C" int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                                int32_t out_act, const float* draw, float noise_std, float noise_clip, float* acts,
+                                float* out2, int64_t ld_out2, pqlk_stream_t stream) {
+  int rc = desc_ok(d);
+  if (rc) return rc;
+  PQLK_REQUIRE(params && x && acts, PQLK_E_NULL);
+  PQLK_REQUIRE(b > 0 && b < (1LL << 30), PQLK_E_SHAPE);
+  PQLK_REQUIRE(ldx % 32 == 0 && ldx >= pqlk_ld(d->dims[0]), PQLK_E_ALIGN);
+  PQLK_REQUIRE(pqlk_aligned16(params) && pqlk_aligned16(x) && pqlk_aligned16(acts), PQLK_E_ALIGN);
+  PQLK_REQUIRE(out_act == PQLK_ACT_NONE || out_act == PQLK_ACT_TANH || out_act == PQLK_ACT_TANH_NOISE, PQLK_E_UNSUPPORTED);
+  if (out_act == PQLK_ACT_TANH_NOISE) PQLK_REQUIRE(draw, PQLK_E_NULL);
+  if (out2) PQLK_REQUIRE(d->n_nets == 1 && ld_out2 >= d->dims[d->n_layers], PQLK_E_SHAPE);
+  const int64_t net_stride = pqlk_mlp_net_stride(d);
+  const int L = d->n_layers;
+  for (int l = 0; l < L; ++l) {
+    int64_t w_off, b_off, a_off, a_ld;
+    pqlk_mlp_layer_offsets(d, l, &w_off, &b_off);
+    pqlk_mlp_act_offset(d, b, 0, l, &a_off, &a_ld);
+    GemmP p = {};
+    if (l == 0) {
+      p.A = x; p.lda = (int)ldx; p.sA = 0;
+    } else {
+      int64_t i_off, i_ld;
+      pqlk_mlp_act_offset(d, b, 0, l - 1, &i_off, &i_ld);
+      p.A = acts + i_off; p.lda = (int)i_ld; p.sA = b * i_ld;
+    }
+    p.B = params + w_off; p.ldb = (int)pqlk_ld(d->dims[l]); p.sB = net_stride;
+    p.bias = params + b_off; p.sBias = net_stride;
+    p.C = acts + a_off; p.ldc = (int)a_ld; p.sC = b * a_ld;
+    p.M = (int)b; p.N = d->dims[l + 1]; p.K = (int)pqlk_ld(d->dims[l]);
+    p.ncols_store = (int)a_ld;
+    p.groups = d->n_nets;
+    p.epi = EPI_ELU;
+    if (l == L - 1) {
+      p.epi = out_act == PQLK_ACT_TANH ? EPI_TANH : (out_act == PQLK_ACT_TANH_NOISE ? EPI_TANH_NOISE : EPI_NONE);
+      p.aux = draw; p.sAux = 0;
+      p.noise_std = noise_std; p.noise_clip = noise_clip;
+      p.C2 = out2; p.ldc2 = (int)ld_out2;
+    }
+    rc = launch_auto<MODE_FWD>(p, d->n_nets, pqlk_s(stream));
+    if (rc) return rc;
+  }
+  return PQLK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sum the split slabs in fixed order -> gradient arena (deterministic)
+__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slabs, int splits, long long n,
+                                                      float* __restrict__ out) {
+  const long long n4 = n >> 2;  // arena sizes are multiples of 32 floats
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    float4 s = reinterpret_cast<const float4*>(slabs)[i];
+    for (int k = 1; k < splits; ++k) {
+      const float4 t = reinterpret_cast<const float4*>(slabs + (long long)k * n)[i];
+      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = s;
+  }
+}
+
+extern "C" int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                                 const float* acts, const float* dy, float* grads, int32_t splits, float* dx,
+                                 int64_t ld_dx, int32_t dx_col0, int32_t dx_cols, const float* dx_tanh_of,
+                                 int64_t ld_tanh, float* ws, int64_t ws_floats, pqlk_stream_t stream) {
+  int rc = desc_ok(d);
+  if (rc) return rc;
+  PQLK_REQUIRE(params && x && acts && dy && ws, PQLK_E_NULL);
+  PQLK_REQUIRE(b > 0 && b < (1LL << 30), PQLK_E_SHAPE);
+  PQLK_REQUIRE(ldx % 32 == 0 && ldx >= pqlk_ld(d->dims[0]), PQLK_E_ALIGN);
+  PQLK_REQUIRE(grads || dx, PQLK_E_NULL);
+  if (grads) PQLK_REQUIRE(splits >= 1 && splits <= 64, PQLK_E_SHAPE);
+  if (!grads) splits = 0;
+  PQLK_REQUIRE(ws_floats >= 2 * (int64_t)d->n_nets * b * max_hidden_ld(d) + (int64_t)splits * pqlk_mlp_param_floats(d),
+               PQLK_E_WORKSPACE);
+  if (dx) {
+    PQLK_REQUIRE(ld_dx % 32 == 0, PQLK_E_ALIGN);
+    if (dx_tanh_of) PQLK_REQUIRE(dx_col0 >= 0 && dx_cols > 0 && dx_col0 + dx_cols <= d->dims[0] && ld_dx >= dx_cols,
+                                 PQLK_E_RANGE);
+    else PQLK_REQUIRE(ld_dx >= pqlk_ld(d->dims[0]), PQLK_E_SHAPE);
+  }
+  const int64_t net_stride = pqlk_mlp_net_stride(d);
+  const int64_t arena = net_stride * d->n_nets;
+  const int L = d->n_layers;
+  const int64_t dbuf = (int64_t)d->n_nets * b * max_hidden_ld(d);
+  float* dact[2] = {ws, ws + dbuf};
+  float* slabs = ws + 2 * dbuf;
+  hipStream_t st = pqlk_s(stream);
+
+  const float* cur_dy = dy;  // (n_nets, b, ld(out_l))
+  int flip = 0;
+  for (int l = L - 1; l >= 0; --l) {
+    int64_t w_off, b_off;
+    pqlk_mlp_layer_offsets(d, l, &w_off, &b_off);
+    const int64_t ld_out = pqlk_ld(d->dims[l + 1]);
+    const int64_t ld_in = pqlk_ld(d->dims[l]);
+    const float* in;
+    int64_t in_ld, in_stride;
+    if (l == 0) {
+      in = x; in_ld = ldx; in_stride = 0;
+    } else {
+      int64_t i_off;
+      pqlk_mlp_act_offset(d, b, 0, l - 1, &i_off, &in_ld);
+      in = acts + i_off; in_stride = b * in_ld;
+    }
+    if (grads) {  // dW_l, db_l
+      GemmP p = {};
+      p.A = cur_dy; p.lda = (int)ld_out; p.sA = b * ld_out;
+      p.B = in; p.ldb = (int)in_ld; p.sB = in_stride;
+      p.C = slabs + w_off; p.ldc = (int)ld_in; p.sC = net_stride;
+      p.dbias = slabs + b_off; p.sBias = net_stride;
+      p.M = d->dims[l + 1]; p.N = (int)ld_in; p.K = (int)b;
+      p.ncols_store = (int)ld_out;
+      p.groups = d->n_nets; p.splits = splits;
+      p.rows_per_split = (int)pqlk_round_up((b + splits - 1) / splits, KT);
+      p.sSplit = arena;
+      // B operand limit: X has ldx >= ld_in columns; only the first ld_in are wanted.  The loader bounds
+      // columns by p.ldb, so clamp through N: tiles never start beyond N and pads inside ldb are zero.
+      rc = launch_auto<MODE_DW>(p, d->n_nets * splits, st);
+      if (rc) return rc;
+    }
+    if (l > 0) {  // dH_{l-1} = (dY_l W_l) * ELU'(H_{l-1})
+      GemmP p = {};
+      p.A = cur_dy; p.lda = (int)ld_out; p.sA = b * ld_out;
+      p.B = params + w_off; p.ldb = (int)ld_in; p.sB = net_stride;
+      p.C = dact[flip]; p.ldc = (int)ld_in; p.sC = b * ld_in;
+      p.aux = in; p.ldaux = (int)in_ld; p.sAux = in_stride;
+      p.M = (int)b; p.N = d->dims[l]; p.K = d->dims[l + 1];
+      p.ncols_store = (int)ld_in;
+      p.groups = d->n_nets; p.zsum = 0;
+      p.epi = EPI_DELU;
+      rc = launch_auto<MODE_DX>(p, d->n_nets, st);
+      if (rc) return rc;
+      cur_dy = dact[flip];
+      flip ^= 1;
+    } else if (dx) {  // input gradient, summed over nets
+      GemmP p = {};
+      p.A = cur_dy; p.lda = (int)ld_out; p.sA = b * ld_out;
+      p.B = params + w_off; p.ldb = (int)ld_in; p.sB = net_stride;
+      p.C = dx; p.ldc = (int)ld_dx; p.sC = 0;
+      p.M = (int)b; p.N = d->dims[0]; p.K = d->dims[1];
+      p.ncols_store = (int)ld_in;
+      p.groups = d->n_nets; p.zsum = 1;
+      if (dx_tanh_of) {
+        p.epi = EPI_DTANH_SLICE; p.aux = dx_tanh_of; p.ldaux = (int)ld_tanh; p.col0 = dx_col0; p.ncol = dx_cols;
+      } else {
+        p.epi = EPI_NONE;
+      }
+      rc = launch_auto<MODE_DX>(p, 1, st);
+      if (rc) return rc;
+    }
+  }
+  if (grads) {
+    int blocks = (int)((arena / 4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, st, slabs, splits, (long long)arena, grads);
+    PQLK_LAUNCH_CHECK();
+  }
+  return PQLK_OK;
+}

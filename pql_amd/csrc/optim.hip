@@ -1,0 +1,191 @@
+// Optimiser over flat arenas: global-norm clip + AdamW (+ Polyak), Polyak alone, batch moments.
+// Reference: torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW(defaults) as called at
+// pql/algo/pql_v_learner.py:124-133 / pql_p_learner.py:87-96; soft_update pql/utils/torch_util.py:9-12;
+// RunningMeanStd.update pql/utils/torch_util.py:77-81.
+// HBM-bound: 20 B read + 16 B written per parameter (+4 B for the norm pass); the reference issues
+// ~100 small launches for the same work.
+#include "pqlk_common.h"
+
+#define OPT_MAX_BLOCKS 1024
+
+__global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int64_t n, float* __restrict__ part,
+                                               int32_t* __restrict__ step_dev) {
+  __shared__ float shw[4];
+  const int64_t n4 = n >> 2;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0) {  // tail (n is a multiple of 32 for MLP arenas; kept for generality)
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 256) acc += g[i] * g[i];
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = (shw[0] + shw[1]) + (shw[2] + shw[3]);
+    if (blockIdx.x == 0 && step_dev) step_dev[0] += 1;  // t for the update kernel that follows on the stream
+  }
+}
+
+struct AdamC {
+  float lr_wd_decay;  // 1 - lr*wd
+  float w1;           // 1 - b1      (lerp weight)
+  float b2, one_m_b2;
+  float eps, tau, one_m_tau;
+  float max_norm;
+  double lr, b1d, b2d;
+};
+
+__global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                               float* __restrict__ v, float* __restrict__ target, int64_t n,
+                                               const float* __restrict__ part, int nparts, AdamC c,
+                                               const int32_t* __restrict__ step_dev, float* __restrict__ gnorm_out) {
+  __shared__ float sh[256];
+  __shared__ float s_coef, s_step_size, s_bc2_sqrt;
+  // every block re-reduces the (<= 1024) partials in the same fixed order -> identical clip factor
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float total = sqrtf(sh[0]);
+    float coef = 1.f;
+    if (c.max_norm > 0.f) coef = fminf(c.max_norm / (total + 1e-6f), 1.f);  // clip_grad_norm_
+    s_coef = coef;
+    const int t = step_dev[0];
+    const double bc1 = 1.0 - pow(c.b1d, (double)t);
+    const double bc2 = 1.0 - pow(c.b2d, (double)t);
+    s_step_size = (float)(c.lr / bc1);
+    s_bc2_sqrt = (float)sqrt(bc2);
+    if (blockIdx.x == 0 && gnorm_out) gnorm_out[0] = total;
+  }
+  __syncthreads();
+  const float coef = s_coef, step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float gi = g[i] * coef;
+    float pi = p[i] * c.lr_wd_decay;                 // p.mul_(1 - lr*wd)
+    float mi = m[i];
+    mi = mi + c.w1 * (gi - mi);                      // m.lerp_(g, 1-b1)
+    float vi = v[i] * c.b2 + (c.one_m_b2 * gi) * gi; // v.mul_(b2).addcmul_(g, g, 1-b2)
+    const float denom = sqrtf(vi) / bc2_sqrt + c.eps;
+    pi = pi + (-step_size) * (mi / denom);           // p.addcdiv_(m, denom, -lr/bc1)
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+    if (target) target[i] = pi * c.tau + target[i] * c.one_m_tau;  // soft_update
+  }
+}
+
+extern "C" int pqlk_clip_adamw_polyak(float* p, float* g, float* m, float* v, float* target, int64_t n, float max_norm,
+                                      float lr, float b1, float b2, float eps, float wd, float tau, int32_t* step_dev,
+                                      float* gnorm_out, float* scratch, pqlk_stream_t stream) {
+  PQLK_REQUIRE(p && g && m && v && step_dev && scratch, PQLK_E_NULL);
+  PQLK_REQUIRE(n > 0, PQLK_E_SHAPE);
+  PQLK_REQUIRE(pqlk_aligned16(g), PQLK_E_ALIGN);
+  int blocks = (int)((n / 4 + 255) / 256);
+  if (blocks < 1) blocks = 1;
+  if (blocks > OPT_MAX_BLOCKS) blocks = OPT_MAX_BLOCKS;
+  hipLaunchKernelGGL(k_sumsq, dim3(blocks), dim3(256), 0, pqlk_s(stream), g, n, scratch, step_dev);
+  PQLK_LAUNCH_CHECK();
+  AdamC c;
+  // scalar constants are formed in double (python floats in torch) and rounded once to fp32
+  c.lr_wd_decay = (float)(1.0 - (double)lr * (double)wd);
+  c.w1 = (float)(1.0 - (double)b1);
+  c.b2 = b2;
+  c.one_m_b2 = (float)(1.0 - (double)b2);
+  c.eps = eps;
+  c.tau = tau;
+  c.one_m_tau = (float)(1.0 - (double)tau);
+  c.max_norm = max_norm;
+  c.lr = (double)lr;
+  c.b1d = (double)b1;
+  c.b2d = (double)b2;
+  int blocks2 = (int)((n + 255) / 256);
+  if (blocks2 > 2048) blocks2 = 2048;
+  hipLaunchKernelGGL(k_adamw, dim3(blocks2), dim3(256), 0, pqlk_s(stream), p, g, m, v, target, n, scratch, blocks, c,
+                     step_dev, gnorm_out);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}
+
+__global__ __launch_bounds__(256) void k_polyak(float* __restrict__ target, const float* __restrict__ cur, int64_t n,
+                                                float tau, float one_m_tau) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    target[i] = cur[i] * tau + target[i] * one_m_tau;
+}
+
+extern "C" int pqlk_polyak(float* target, const float* cur, int64_t n, float tau, pqlk_stream_t stream) {
+  PQLK_REQUIRE(target && cur, PQLK_E_NULL);
+  PQLK_REQUIRE(n > 0, PQLK_E_SHAPE);
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_polyak, dim3(blocks), dim3(256), 0, pqlk_s(stream), target, cur, n, tau,
+                     (float)(1.0 - (double)tau));
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch mean / unbiased variance per column.  Block = 32 columns x 8 row-lanes, two passes.
+__global__ __launch_bounds__(256) void k_batch_moments(const float* __restrict__ x, int64_t ldx, int64_t n, int cols,
+                                                       float* __restrict__ mean_out, float* __restrict__ var_out) {
+  __shared__ float sh[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + cx;
+  float s = 0.f;
+  if (col < cols)
+    for (int64_t r = ry; r < n; r += 8) s += x[r * ldx + col];
+  sh[ry][cx] = s;
+  __syncthreads();
+  float mean = 0.f;
+  for (int k = 0; k < 8; ++k) mean += sh[k][cx];
+  mean /= (float)n;
+  __syncthreads();
+  float q = 0.f;
+  if (col < cols)
+    for (int64_t r = ry; r < n; r += 8) {
+      const float d = x[r * ldx + col] - mean;
+      q += d * d;
+    }
+  sh[ry][cx] = q;
+  __syncthreads();
+  if (ry == 0 && col < cols) {
+    float t = 0.f;
+    for (int k = 0; k < 8; ++k) t += sh[k][cx];
+    mean_out[col] = mean;
+    var_out[col] = t / (float)(n - 1);
+  }
+}
+
+extern "C" int pqlk_batch_moments(const float* x, int64_t ldx, int64_t n, int32_t cols, float* mean_out, float* var_out,
+                                  pqlk_stream_t stream) {
+  PQLK_REQUIRE(x && mean_out && var_out, PQLK_E_NULL);
+  PQLK_REQUIRE(n >= 2 && cols > 0 && ldx >= cols, PQLK_E_SHAPE);
+  hipLaunchKernelGGL(k_batch_moments, dim3((cols + 31) / 32), dim3(256), 0, pqlk_s(stream), x, ldx, n, (int)cols, mean_out,
+                     var_out);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int pqlk_version(void) { return PQLK_VERSION; }
+
+extern "C" const char* pqlk_strerror(int rc) {
+  if (rc == 0) return "ok";
+  if (rc < 0) return hipGetErrorString((hipError_t)(-rc));
+  switch (rc) {
+    case PQLK_E_NULL: return "pqlk: required pointer is NULL";
+    case PQLK_E_SHAPE: return "pqlk: bad or inconsistent dimension";
+    case PQLK_E_RANGE: return "pqlk: index or offset out of range";
+    case PQLK_E_ALIGN: return "pqlk: leading dimension not a multiple of 32 or pointer not 16-byte aligned";
+    case PQLK_E_UNSUPPORTED: return "pqlk: unsupported configuration";
+    case PQLK_E_WORKSPACE: return "pqlk: workspace too small";
+    default: return "pqlk: unknown error";
+  }
+}

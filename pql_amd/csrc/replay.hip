@@ -1,0 +1,236 @@
+// Replay ring kernels: insert, plain gather, fused gather+normalise+concat.
+// Reference behaviour: pql/replay/simple_replay.py:40-104, pql/algo/pql_p_learner.py:49-50,66-85,
+// pql/utils/common.py:139-145.  HBM-bound byte movement: one wave per record, 16-B lane accesses,
+// records 128-B aligned so a random sample touches the minimum number of HBM lines.
+#include "pqlk_common.h"
+
+extern "C" int64_t pqlk_ld(int64_t cols) { return pqlk_round_up(cols < 1 ? 1 : cols, 32); }
+
+extern "C" int64_t pqlk_replay_rec_ld(int32_t obs_dim, int32_t act_dim) {
+  if (obs_dim <= 0) return 0;
+  return rec_layout(obs_dim, act_dim).ld;
+}
+
+// ------------------------------------------------------------------------------------------------
+// insert: row r of the five source arrays -> record (dst_start + r).  One wave per record.
+__global__ __launch_bounds__(256) void k_replay_insert(float* __restrict__ records, RecLayout L, int64_t dst_start,
+                                                       int64_t m, const float* __restrict__ obs, int64_t ld_obs,
+                                                       const float* __restrict__ act, int64_t ld_act,
+                                                       const float* __restrict__ rew, int64_t ld_rew,
+                                                       const float* __restrict__ nobs, int64_t ld_nobs,
+                                                       const float* __restrict__ done, int64_t ld_done) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t r = wave; r < m; r += nwaves) {
+    float* rec = records + (dst_start + r) * L.ld;
+    for (int c = lane; c < L.ld; c += 64) {
+      float v = 0.f;
+      if (c < L.O) {
+        v = obs[r * ld_obs + c];
+      } else if (L.A >= 0) {
+        if (c >= L.off_nobs && c < L.off_nobs + L.O) v = nobs[r * ld_nobs + (c - L.off_nobs)];
+        else if (c >= L.off_act && c < L.off_act + L.A) v = act[r * ld_act + (c - L.off_act)];
+        else if (c == L.off_rd) v = rew[r * ld_rew];
+        else if (c == L.off_rd + 1) v = (done[r * ld_done] != 0.f) ? 1.f : 0.f;  // .bool() then .float()
+      }
+      rec[c] = v;
+    }
+  }
+}
+
+extern "C" int pqlk_replay_insert(const PqlReplayDesc* ring, int64_t dst_start, int64_t m, const float* obs,
+                                  int64_t ld_obs, const float* act, int64_t ld_act, const float* rew, int64_t ld_rew,
+                                  const float* next_obs, int64_t ld_nobs, const float* done, int64_t ld_done,
+                                  pqlk_stream_t stream) {
+  PQLK_REQUIRE(ring && ring->records && obs, PQLK_E_NULL);
+  PQLK_REQUIRE(ring->obs_dim > 0 && ring->capacity > 0 && m >= 0, PQLK_E_SHAPE);
+  RecLayout L = rec_layout(ring->obs_dim, ring->act_dim);
+  PQLK_REQUIRE(ring->rec_ld == L.ld, PQLK_E_SHAPE);
+  PQLK_REQUIRE(dst_start >= 0 && dst_start + m <= ring->capacity, PQLK_E_RANGE);
+  if (L.A >= 0) PQLK_REQUIRE(act && rew && next_obs && done, PQLK_E_NULL);
+  PQLK_REQUIRE(ld_obs >= L.O, PQLK_E_SHAPE);
+  if (m == 0) return PQLK_OK;
+  int64_t blocks = (m + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_replay_insert, dim3((unsigned)blocks), dim3(256), 0, pqlk_s(stream), ring->records, L, dst_start, m,
+                     obs, ld_obs, act, ld_act, rew, ld_rew, next_obs, ld_nobs, done, ld_done);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// plain gather: five contiguous outputs, byte-exact copies (done already 0.0/1.0).
+__global__ __launch_bounds__(256) void k_replay_gather(const float* __restrict__ records, RecLayout L, int64_t capacity,
+                                                       const int64_t* __restrict__ idx, int64_t b,
+                                                       float* __restrict__ o_obs, float* __restrict__ o_act,
+                                                       float* __restrict__ o_rew, float* __restrict__ o_nobs,
+                                                       float* __restrict__ o_done) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t r = wave; r < b; r += nwaves) {
+    int64_t src = idx[r];
+    if (src < 0 || src >= capacity) src = 0;  // never fault on a bad index; host validates in debug paths
+    const float4* rec4 = reinterpret_cast<const float4*>(records + src * L.ld);
+    const int nchunk = L.used >> 2;
+    for (int q = lane; q < nchunk; q += 64) {
+      float4 v = rec4[q];
+      const float e[4] = {v.x, v.y, v.z, v.w};
+      const int c = q << 2;
+      if (c < L.o4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < L.O) o_obs[r * L.O + c + j] = e[j];
+      } else if (L.A >= 0) {
+        if (c < L.off_act) {
+          const int cc = c - L.off_nobs;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (cc + j < L.O) o_nobs[r * L.O + cc + j] = e[j];
+        } else if (c < L.off_rd) {
+          const int cc = c - L.off_act;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (cc + j < L.A) o_act[r * L.A + cc + j] = e[j];
+        } else {
+          o_rew[r] = e[0];
+          o_done[r] = e[1];
+        }
+      }
+    }
+  }
+}
+
+extern "C" int pqlk_replay_gather(const PqlReplayDesc* ring, const int64_t* idx, int64_t b, float* obs, float* act,
+                                  float* rew, float* next_obs, float* done, pqlk_stream_t stream) {
+  PQLK_REQUIRE(ring && ring->records && idx && obs, PQLK_E_NULL);
+  PQLK_REQUIRE(ring->obs_dim > 0 && ring->capacity > 0 && b >= 0, PQLK_E_SHAPE);
+  RecLayout L = rec_layout(ring->obs_dim, ring->act_dim);
+  PQLK_REQUIRE(ring->rec_ld == L.ld, PQLK_E_SHAPE);
+  if (L.A >= 0) PQLK_REQUIRE(act && rew && next_obs && done, PQLK_E_NULL);
+  if (b == 0) return PQLK_OK;
+  int64_t blocks = (b + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_replay_gather, dim3((unsigned)blocks), dim3(256), 0, pqlk_s(stream), ring->records, L,
+                     ring->capacity, idx, b, obs, act, rew, next_obs, done);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused gather: sample + normalise (+-5 clamp) + concat into the padded GEMM input tiles.
+__device__ __forceinline__ float norm1(float x, float mean, float var, float eps, int clamp5) {
+  float y = (x - mean) / sqrtf(var + eps);  // IEEE div/sqrt: bit-identical to torch CPU fp32
+  if (clamp5) y = fminf(fmaxf(y, -5.f), 5.f);
+  return y;
+}
+
+template <bool HAS_NORM>
+__global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __restrict__ records, RecLayout L,
+                                                             int64_t capacity, const int64_t* __restrict__ idx, int64_t b,
+                                                             const float* __restrict__ mean, const float* __restrict__ var,
+                                                             float eps, int clamp5, float* __restrict__ x_sa, int64_t ld_sa,
+                                                             float* __restrict__ xn_sa, float* __restrict__ xn_obs,
+                                                             int64_t ld_o, float* __restrict__ o_rew,
+                                                             float* __restrict__ o_done) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int nchunk = L.used >> 2;
+  const int A = L.A < 0 ? 0 : L.A;
+  const int sa_cols = L.O + A;
+  for (int64_t r = wave; r < b; r += nwaves) {
+    int64_t src = idx[r];
+    if (src < 0 || src >= capacity) src = 0;
+    const float4* rec4 = reinterpret_cast<const float4*>(records + src * L.ld);
+    float* xs = x_sa ? x_sa + r * ld_sa : nullptr;
+    float* xns = xn_sa ? xn_sa + r * ld_sa : nullptr;
+    float* xno = xn_obs ? xn_obs + r * ld_o : nullptr;
+    for (int q = lane; q < nchunk; q += 64) {
+      float4 v = rec4[q];
+      float e[4] = {v.x, v.y, v.z, v.w};
+      const int c = q << 2;
+      if (c < L.o4) {  // obs
+        if (HAS_NORM) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (c + j < L.O) e[j] = norm1(e[j], mean[c + j], var[c + j], eps, clamp5);
+        }
+        if (L.A < 0) {  // obs-only ring: the sample IS the learner's obs batch
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (c + j < L.O) {
+              if (xs) xs[c + j] = e[j];
+              if (xno) xno[c + j] = e[j];
+            }
+        } else if (xs) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (c + j < L.O) xs[c + j] = e[j];
+        }
+      } else if (L.A >= 0) {
+        if (c < L.off_act) {  // next_obs
+          const int cc = c - L.off_nobs;
+          if (HAS_NORM) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (cc + j < L.O) e[j] = norm1(e[j], mean[cc + j], var[cc + j], eps, clamp5);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (cc + j < L.O) {
+              if (xns) xns[cc + j] = e[j];
+              if (xno) xno[cc + j] = e[j];
+            }
+        } else if (c < L.off_rd) {  // action -> columns O.. of the critic input
+          const int cc = c - L.off_act;
+          if (xs) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (cc + j < L.A) xs[L.O + cc + j] = e[j];
+          }
+        } else {
+          if (o_rew) o_rew[r] = e[0];
+          if (o_done) o_done[r] = e[1];
+        }
+      }
+    }
+    // zero the pad columns so the GEMM K-loop can run over the padded width unchecked
+    for (int c = sa_cols + lane; c < ld_sa; c += 64) {
+      if (xs) xs[c] = 0.f;
+      if (xns) xns[c] = 0.f;
+    }
+    if (L.A < 0 && xs) {
+      for (int c = L.O + lane; c < sa_cols; c += 64) xs[c] = 0.f;
+    }
+    if (xno)
+      for (int c = L.O + lane; c < ld_o; c += 64) xno[c] = 0.f;
+  }
+}
+
+extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t* idx, int64_t b, const float* mean,
+                                        const float* var, float eps, int clamp5, float* x_sa, int64_t ld_sa,
+                                        float* xn_sa, float* xn_obs, int64_t ld_o, float* rew, float* done,
+                                        pqlk_stream_t stream) {
+  PQLK_REQUIRE(ring && ring->records && idx, PQLK_E_NULL);
+  PQLK_REQUIRE(ring->obs_dim > 0 && ring->capacity > 0 && b >= 0, PQLK_E_SHAPE);
+  RecLayout L = rec_layout(ring->obs_dim, ring->act_dim);
+  PQLK_REQUIRE(ring->rec_ld == L.ld, PQLK_E_SHAPE);
+  PQLK_REQUIRE((mean == nullptr) == (var == nullptr), PQLK_E_NULL);
+  if (x_sa || xn_sa) PQLK_REQUIRE(ld_sa % 32 == 0 && ld_sa >= L.O + (L.A < 0 ? 0 : L.A), PQLK_E_ALIGN);
+  if (xn_obs) PQLK_REQUIRE(ld_o % 32 == 0 && ld_o >= L.O, PQLK_E_ALIGN);
+  if (L.A < 0) PQLK_REQUIRE(xn_sa == nullptr, PQLK_E_UNSUPPORTED);
+  if (b == 0) return PQLK_OK;
+  int64_t blocks = (b + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  if (mean)
+    hipLaunchKernelGGL(k_replay_gather_fused<true>, dim3((unsigned)blocks), dim3(256), 0, pqlk_s(stream), ring->records,
+                       L, ring->capacity, idx, b, mean, var, eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done);
+  else
+    hipLaunchKernelGGL(k_replay_gather_fused<false>, dim3((unsigned)blocks), dim3(256), 0, pqlk_s(stream),
+                       ring->records, L, ring->capacity, idx, b, mean, var, eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o,
+                       rew, done);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}

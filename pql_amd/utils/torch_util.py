@@ -1,0 +1,68 @@
+"""`soft_update` and `RunningMeanStd` with the reference's names (pql/utils/torch_util.py:9-12, :68-114)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from pql_amd import _lib as L
+
+
+@torch.no_grad()
+def soft_update(target_net, current_net, tau: float):
+    """theta' <- tau*theta + (1-tau)*theta'.  One launch over the flat arenas when both nets are
+    pql_amd FusedMLP modules; any other nn.Module pair is rejected loudly (no eager fallback)."""
+    ta, ca = getattr(target_net, "arena", None), getattr(current_net, "arena", None)
+    if ta is None or ca is None:
+        raise L.PqlkError("soft_update needs pql_amd models (flat parameter arenas)")
+    with torch.cuda.device(ta.device):
+        L.check(L.lib.pqlk_polyak(L.ptr(ta.data), L.ptr(ca.data), ta.numel(), float(tau), L.stream(ta.device)))
+
+
+class RunningMeanStd:
+    """Running per-feature mean/variance with the parallel (Chan) merge; count starts at epsilon.
+    Batch moments come from one HIP launch (pqlk_batch_moments); the O(obs_dim) merge is torch."""
+
+    def __init__(self, epsilon=1e-4, shape=(), device="cuda"):
+        self.device = torch.device(device)
+        self.mean = torch.zeros(shape, device=self.device)
+        self.var = torch.ones(shape, device=self.device)
+        self.epsilon = epsilon
+        self.count = epsilon
+
+    def batch_moments(self, x):
+        x = x.reshape(x.shape[0], -1)
+        cols = x.shape[1]
+        bm = torch.empty(cols, dtype=torch.float32, device=x.device)
+        bv = torch.empty(cols, dtype=torch.float32, device=x.device)
+        x = x.contiguous()
+        with torch.cuda.device(x.device):
+            L.check(L.lib.pqlk_batch_moments(L.ptr(x), x.stride(0), x.shape[0], cols, L.ptr(bm), L.ptr(bv),
+                                             L.stream(x.device)))
+        return bm.view(self.mean.shape), bv.view(self.mean.shape)
+
+    def update(self, x):
+        bm, bv = self.batch_moments(x)
+        self.update_from_moments(bm, bv, x.shape[0])
+
+    def update_from_moments(self, batch_mean, batch_var, batch_count):
+        delta = batch_mean - self.mean
+        tot = self.count + batch_count
+        m2 = self.var * self.count + batch_var * batch_count + delta ** 2 * self.count * batch_count / tot
+        self.mean = self.mean + delta * batch_count / tot
+        self.var = m2 / tot
+        self.count = tot
+
+    def normalize(self, x):
+        return (x - self.mean) / torch.sqrt(self.var + self.epsilon)  # actor side: no clamp (torch_util.py:83-85)
+
+    def unnormalize(self, x):
+        return x * torch.sqrt(self.var + self.epsilon) + self.mean
+
+    def get_states(self, device=None):
+        if device is not None:
+            return self.mean.to(device), self.var.to(device), self.epsilon
+        return self.mean, self.var, self.epsilon
+
+    def load_state_dict(self, info):
+        self.mean, self.var, self.count = info[0], info[1], info[2]

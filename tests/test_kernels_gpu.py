@@ -1,0 +1,403 @@
+"""Parity of the HIP kernels (through the C ABI / ctypes) against the CPU oracle and the committed
+golden vectors.  Needs an MI355X: run with `pytest -m gpu`.
+
+Bars: bit-exact for byte/index work (ring, gather, normalise, n-step); fp32 MLP outputs within 1e-5 of
+the reference (north_star); gradients / optimiser within the rtol/atol written at each assert."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import detdata as dd
+
+pytestmark = pytest.mark.gpu
+
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import pql_ref_cpu
+    return pql_ref_cpu
+
+
+# --------------------------------------------------------------------------- ring
+@pytest.mark.parametrize("name", ["wrap4", "exact", "ragged"])
+def test_ring_insert_and_sample(golden, dev, name):
+    from pql_amd.replay.simple_replay import ReplayBuffer
+    g = golden("replay")
+    cap, O, A = (int(v) for v in g[f"ring_{name}_meta"])
+    rb = ReplayBuffer(cap, (O,), A, device=dev)
+    for step, m in enumerate(g[f"ring_{name}_inserts"]):
+        seed = 100 + step
+        traj = (T(dd.uniform((m, O), seed)), T(dd.uniform((m, A), seed + 20)), T(dd.uniform((m, 1), seed + 40)),
+                T(dd.uniform((m, O), seed + 60)), T(dd.bernoulli((m, 1), seed + 80, 0.3)))
+        rb.add_to_buffer(tuple(t.to(dev) for t in traj))
+        assert [rb.next_p, rb.cur_capacity, int(rb.if_full)] == g[f"ring_{name}_trace"][step].tolist()
+    for nm, t in (("obs", rb.buf_obs), ("act", rb.buf_action), ("rew", rb.buf_reward), ("nobs", rb.buf_next_obs),
+                  ("done", rb.buf_done)):
+        assert np.array_equal(t.cpu().numpy(), g[f"ring_{name}_{nm}"]), nm
+    out = rb.sample_batch(16, device=dev, indices=T(g[f"ring_{name}_idx"]))
+    for nm, t in zip(("s_obs", "s_act", "s_rew", "s_nobs", "s_done"), out):
+        assert t.dtype == torch.float32 and t.is_cuda
+        assert np.array_equal(t.cpu().numpy(), g[f"ring_{name}_{nm}"]), nm
+    # un-injected: exactly one int64 randint draw of shape (B,) on the ring's device (Appendix B)
+    torch.manual_seed(7)
+    expect = torch.randint(rb.cur_capacity, size=(16,), device=dev)
+    torch.manual_seed(7)
+    assert torch.equal(rb.draw_indices(16), expect)
+
+
+def test_ring_rejects_cpu_and_oversize(dev):
+    from pql_amd._lib import PqlkError
+    from pql_amd.replay.simple_replay import ReplayBuffer
+    with pytest.raises(PqlkError):
+        ReplayBuffer(10, (3,), 2, device="cpu")
+    rb = ReplayBuffer(10, (3,), 2, device=dev)
+    z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+    with pytest.raises(RuntimeError):
+        rb.add_to_buffer((z(25, 3), z(25, 2), z(25, 1), z(25, 3), z(25, 1)))
+
+
+@pytest.mark.parametrize("O,A", [(8, 2), (88, 16), (211, 20), (108, 21)])
+def test_gather_fused_bit_exact(dev, ref, O, A):
+    """sample + normalize(+-5 clamp) + cat, vs oracle; ragged O/A exercise the unaligned field paths."""
+    from pql_amd import _lib as L
+    from pql_amd.replay.simple_replay import ReplayBuffer
+    cap, B = 500, 77
+    rb = ReplayBuffer(cap, (O,), A, device=dev)
+    ring = ref.RingRef(cap, O, A)
+    data = (T(dd.uniform((cap, O), 1, -30, 30)), T(dd.uniform((cap, A), 2)), T(dd.uniform((cap, 1), 3)),
+            T(dd.uniform((cap, O), 4, -30, 30)), T(dd.bernoulli((cap, 1), 5, 0.3)))
+    rb.add_to_buffer(tuple(t.to(dev) for t in data)); ring.insert(*data)
+    idx = T(dd.integers((B,), 6, cap))
+    mean, var = T(dd.uniform((O,), 7)), T(dd.uniform((O,), 8, 0.01, 4.0))
+    o, a, r, no, d = ring.gather(idx)
+    on, non = ref.normalize_ref(o, (mean, var, 1e-4)), ref.normalize_ref(no, (mean, var, 1e-4))
+    ld_sa, ld_o = L.ld(O + A), L.ld(O)
+    f = dict(dtype=torch.float32, device=dev)
+    x_sa = torch.full((B, ld_sa), 9.0, **f); xn_sa = torch.full((B, ld_sa), 9.0, **f); xn_o = torch.full((B, ld_o), 9.0, **f)
+    rew = torch.empty(B, **f); done = torch.empty(B, **f)
+    L.check(L.lib.pqlk_replay_gather_fused(C.byref(rb.ring.desc), L.ptr(idx.to(dev)), B, L.ptr(mean.to(dev)),
+                                           L.ptr(var.to(dev)), 1e-4, 1, L.ptr(x_sa), ld_sa, L.ptr(xn_sa), L.ptr(xn_o), ld_o,
+                                           L.ptr(rew), L.ptr(done), L.stream(dev)))
+    x_sa, xn_sa, xn_o = x_sa.cpu(), xn_sa.cpu(), xn_o.cpu()
+    assert torch.equal(x_sa[:, :O], on) and torch.equal(x_sa[:, O:O + A], a)
+    assert torch.all(x_sa[:, O + A:] == 0)
+    assert torch.equal(xn_sa[:, :O], non) and torch.all(xn_sa[:, O:O + A] == 9.0) and torch.all(xn_sa[:, O + A:] == 0)
+    assert torch.equal(xn_o[:, :O], non) and torch.all(xn_o[:, O:] == 0)
+    assert torch.equal(rew.cpu(), r.view(-1)) and torch.equal(done.cpu(), d.view(-1))
+
+
+def test_obs_ring_gather(dev, ref):
+    from pql_amd import _lib as L
+    from pql_amd.replay.simple_replay import RecordRing, ring_plan
+    O, cap, B = 13, 40, 33
+    ring = RecordRing(cap, O, -1, dev)
+    oracle = ref.ObsRingRef(cap, O)
+    next_p, full = 0, False
+    for step, m in enumerate([17, 17, 17]):
+        obs = T(dd.uniform((m, O), 40 + step))
+        segs, next_p, full, cur = ring_plan(next_p, full, cap, m)
+        ring.insert_segments(segs, obs.to(dev))
+        oracle.insert(obs)
+    assert (next_p, cur) == (oracle.next_p, oracle.cur_capacity)
+    assert torch.equal(ring.records[:, :O].cpu(), oracle.mem)
+    idx = T(dd.integers((B,), 9, cur))
+    x_sa = torch.full((B, L.ld(O + 3)), 7.0, device=dev); x_o = torch.full((B, L.ld(O)), 7.0, device=dev)
+    L.check(L.lib.pqlk_replay_gather_fused(C.byref(ring.desc), L.ptr(idx.to(dev)), B, None, None, 0.0, 1, L.ptr(x_sa),
+                                           x_sa.stride(0), None, L.ptr(x_o), x_o.stride(0), None, None, L.stream(dev)))
+    assert torch.equal(x_o[:, :O].cpu(), oracle.gather(idx)) and torch.all(x_o[:, O:] == 0)
+    assert torch.equal(x_sa[:, :O].cpu(), oracle.gather(idx)) and torch.all(x_sa[:, O:] == 0)
+
+
+# --------------------------------------------------------------------------- n-step
+@pytest.mark.parametrize("name", ["kat3", "n3", "n5", "n1"])
+def test_nstep_golden(golden, dev, name):
+    from pql_amd.replay.nstep_replay import NStepReplay
+    g = golden("nstep")
+    meta = g[f"nstep_{name}_meta"]
+    N, n, O, A = (int(v) for v in meta[:4])
+    ns = NStepReplay((O,), A, N, n, device=dev)
+    for ci, Tn in enumerate(int(v) for v in meta[4:]):
+        seed = 500 + 10 * ci
+        obs = dd.uniform((N, Tn, O), seed); act = dd.uniform((N, Tn, A), seed + 1)
+        rew = dd.uniform((N, Tn, 1), seed + 2); nobs = dd.uniform((N, Tn, O), seed + 3)
+        done = dd.bernoulli((N, Tn, 1), seed + 4, 0.25)
+        if name == "kat3":
+            rew, done = g["nstep_kat3_in_rew"], g["nstep_kat3_in_done"]
+        res = ns.add_to_buffer(*(T(a).to(dev) for a in (obs, act, rew, nobs, done)))
+        for nm, t in zip(("obs", "act", "rew", "nobs", "done"), res):
+            exp = g[f"nstep_{name}_c{ci}_{nm}"]
+            assert tuple(t.shape) == exp.shape, (nm, ci)
+            assert np.array_equal(t.cpu().numpy(), exp), (nm, ci)   # bit-exact incl. the fp32 reward sum
+
+
+def test_nstep_first_call_too_short(dev):
+    from pql_amd.replay.nstep_replay import NStepReplay
+    ns = NStepReplay((2,), 1, 3, 3, device=dev)
+    z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+    with pytest.raises(RuntimeError):
+        ns.add_to_buffer(z(3, 2, 2), z(3, 2, 1), z(3, 2, 1), z(3, 2, 2), z(3, 2, 1))
+
+
+def test_nstep_large_vs_oracle(dev, ref):
+    """4096 envs, warm-up T=32 then T=1 calls: every emitted row equals the oracle's."""
+    from pql_amd.replay.nstep_replay import NStepReplay
+    N, n, O, A = 4096, 3, 88, 16
+    ns = NStepReplay((O,), A, N, n, device=dev)
+    orc = ref.NStepRef(O, A, N, n)
+    for ci, Tn in enumerate([32, 1, 1]):
+        s = 9000 + 10 * ci
+        args = [T(dd.uniform((N, Tn, O), s)), T(dd.uniform((N, Tn, A), s + 1)), T(dd.uniform((N, Tn, 1), s + 2)),
+                T(dd.uniform((N, Tn, O), s + 3)), T(dd.bernoulli((N, Tn, 1), s + 4, 0.05))]
+        got = ns.add_to_buffer(*(a.to(dev) for a in args))
+        exp = orc.add(*args)
+        for a, b in zip(got, exp):
+            assert torch.equal(a.cpu(), b)
+
+
+# --------------------------------------------------------------------------- MLP family vs golden
+SHAPES = [(8, 2), (88, 16), (211, 20), (108, 21)]
+
+
+def _sd(state):
+    return {k: T(v) for k, v in state.items()}
+
+
+def _check_grads(module, garena, g, prefix, rtol=2e-4, atol=2e-6):
+    lay = module.layout
+    for n, pre in enumerate(module.key_prefixes):
+        for l in range(lay.n_layers):
+            for kind, view in (("weight", lay.weight(garena, n, l)), ("bias", lay.bias(garena, n, l))):
+                key = f"{pre}{2 * l}.{kind}"
+                np.testing.assert_allclose(dd.summarize(view.cpu().numpy()), g[f"{prefix}{key}"], rtol=rtol, atol=atol,
+                                           err_msg=key)
+
+
+@pytest.mark.parametrize("O,A", SHAPES)
+def test_actor_module(golden, dev, O, A):
+    from pql_amd.models.mlp import TanhMLPPolicy
+    g = golden("models"); tag = f"o{O}a{A}"; B = 33 if O == 8 else 17
+    m = TanhMLPPolicy((O,), A).to(dev); m.load_state_dict(_sd(dd.mlp_state(O, A, 11)))
+    obs = T(dd.uniform((B, O), 1000 + O, -2, 2)).to(dev).requires_grad_(True)
+    y = m(obs)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"actor_{tag}_y"], atol=1e-5)
+    (y * T(dd.uniform((B, A), 3000 + O)).to(dev)).sum().backward()
+    np.testing.assert_allclose(obs.grad.cpu().numpy(), g[f"actor_{tag}_dobs"], atol=2e-6)
+    _check_grads(m, m.arena.grad, g, f"actor_{tag}_g_")
+    # padding invariant: pad columns of W and pad entries of b carry exactly zero gradient
+    in_views = sum(v.abs().sum().item() for v in (m.layout.weight(m.arena.grad, 0, l) for l in range(m.layout.n_layers)))
+    in_views += sum(m.layout.bias(m.arena.grad, 0, l).abs().sum().item() for l in range(m.layout.n_layers))
+    np.testing.assert_allclose(m.arena.grad.abs().sum().item(), in_views, rtol=1e-5)
+
+
+@pytest.mark.parametrize("O,A", SHAPES)
+def test_doubleq_module(golden, dev, O, A):
+    from pql_amd.models.mlp import DoubleQ
+    g = golden("models"); tag = f"o{O}a{A}"; B = 33 if O == 8 else 17
+    q = DoubleQ((O,), A).to(dev); q.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 21)))
+    obs = T(dd.uniform((B, O), 1000 + O, -2, 2)).to(dev).requires_grad_(True)
+    act = T(dd.uniform((B, A), 2000 + O)).to(dev).requires_grad_(True)
+    q1, q2 = q.get_q1_q2(obs, act)
+    np.testing.assert_allclose(q1.detach().cpu().numpy(), g[f"dq_{tag}_q1"], atol=1e-5)   # north_star bar
+    np.testing.assert_allclose(q2.detach().cpu().numpy(), g[f"dq_{tag}_q2"], atol=1e-5)
+    tgt = T(dd.uniform((B, 1), 4000 + O)).to(dev)
+    loss = torch.nn.functional.mse_loss(q1, tgt) + torch.nn.functional.mse_loss(q2, tgt)
+    np.testing.assert_allclose(loss.item(), g[f"dq_{tag}_loss"], rtol=1e-5)
+    loss.backward()
+    np.testing.assert_allclose(obs.grad.cpu().numpy(), g[f"dq_{tag}_dobs"], atol=2e-6)
+    np.testing.assert_allclose(act.grad.cpu().numpy(), g[f"dq_{tag}_dact"], atol=2e-6)
+    _check_grads(q, q.arena.grad, g, f"dq_{tag}_g_")
+    o2 = obs.detach().clone().requires_grad_(True); a2 = act.detach().clone().requires_grad_(True)
+    (-q.get_q_min(o2, a2).mean()).backward()
+    np.testing.assert_allclose(a2.grad.cpu().numpy(), g[f"dq_{tag}_dpg_dact"], atol=2e-7)
+    np.testing.assert_allclose(o2.grad.cpu().numpy(), g[f"dq_{tag}_dpg_dobs"], atol=2e-7)
+    sd = q.state_dict()
+    assert list(sd)[:2] == ["net_q1.net.0.weight", "net_q1.net.0.bias"] and len(sd) == 16
+
+
+@pytest.mark.parametrize("O,A", SHAPES)
+def test_distributional_module(golden, dev, O, A):
+    from pql_amd.models.mlp import DistributionalDoubleQ
+    g = golden("models"); tag = f"o{O}a{A}"; B = 33 if O == 8 else 17; K = 51
+    q = DistributionalDoubleQ((O,), A, v_min=-10, v_max=10, num_atoms=K, device=dev).to(dev)
+    q.load_state_dict(_sd(dd.doubleq_state(O, A, K, 31)))
+    assert np.array_equal(q.z_atoms.cpu().numpy(), g[f"ddq_{tag}_z"])
+    obs = T(dd.uniform((B, O), 1000 + O, -2, 2)).to(dev).requires_grad_(True)
+    act = T(dd.uniform((B, A), 2000 + O)).to(dev).requires_grad_(True)
+    p1, p2 = q.get_q1_q2(obs, act)
+    np.testing.assert_allclose(p1.detach().cpu().numpy(), g[f"ddq_{tag}_p1"], atol=1e-6)
+    np.testing.assert_allclose(p2.detach().cpu().numpy(), g[f"ddq_{tag}_p2"], atol=1e-6)
+    np.testing.assert_allclose(q.get_q_min(obs, act).detach().cpu().numpy(), g[f"ddq_{tag}_qmin"], atol=1e-5)
+    tg = T(g[f"ddq_{tag}_tgt"]).to(dev)
+    loss = torch.nn.functional.binary_cross_entropy(p1, tg) + torch.nn.functional.binary_cross_entropy(p2, tg)
+    loss.backward()
+    np.testing.assert_allclose(obs.grad.cpu().numpy(), g[f"ddq_{tag}_dobs"], atol=2e-6)
+    _check_grads(q, q.arena.grad, g, f"ddq_{tag}_g_")
+
+
+def test_baseline_hidden_shape(golden, dev):
+    from pql_amd.models.mlp import MLPNet
+    g = golden("models"); hid = (512, 512, 256)
+    net = MLPNet(104, 1, hidden_layers=list(hid)).to(dev); net.load_state_dict(_sd(dd.mlp_state(104, 1, 41, hid)))
+    x = T(dd.uniform((9, 104), 6000)).to(dev).requires_grad_(True)
+    y = net(x); y.sum().backward()
+    np.testing.assert_allclose(y.detach().cpu().numpy(), g["mlp_h512_512_256_y"], atol=1e-5)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["mlp_h512_512_256_dx"], atol=2e-6)
+
+
+@pytest.mark.parametrize("B", [8192, 777])
+def test_mlp_full_batch_vs_oracle(dev, ref, B):
+    """BASELINE batch (8192) and a ragged batch: forward within 1e-5, gradients at 1e-4 relative of the
+    oracle (torch CPU autograd) -- exercises the 128x128 tiles, split-batch dW and tail handling."""
+    from pql_amd.models.mlp import DoubleQ
+    O, A = 88, 16
+    q = DoubleQ((O,), A).to(dev); st = dd.doubleq_state(O, A, 1, 21); q.load_state_dict(_sd(st))
+    obs = T(dd.uniform((B, O), 71, -2, 2)); act = T(dd.uniform((B, A), 72))
+    w = T(dd.uniform((2, B, 1), 73))
+    od = obs.to(dev).requires_grad_(True); ad = act.to(dev).requires_grad_(True)
+    y = q._heads(od, ad)
+    (y * w.to(dev)).sum().backward()
+    q1 = [p.requires_grad_(True) for p in ref.params_from_state(st, "net_q1.net.")]
+    q2 = [p.requires_grad_(True) for p in ref.params_from_state(st, "net_q2.net.")]
+    oc = obs.clone().requires_grad_(True); ac = act.clone().requires_grad_(True)
+    a, b = ref.twin_forward_ref(q1, q2, oc, ac)
+    np.testing.assert_allclose(y[0].detach().cpu().numpy(), a.detach().numpy(), atol=1e-5)
+    np.testing.assert_allclose(y[1].detach().cpu().numpy(), b.detach().numpy(), atol=1e-5)
+    gr = torch.autograd.grad((a * w[0]).sum() + (b * w[1]).sum(), [oc, ac, *q1, *q2])
+    np.testing.assert_allclose(od.grad.cpu().numpy(), gr[0].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ad.grad.cpu().numpy(), gr[1].numpy(), rtol=1e-4, atol=1e-5)
+    lay = q.layout
+    k = 2
+    for n in range(2):
+        for l in range(lay.n_layers):
+            gw, gb = gr[k].numpy(), gr[k + 1].numpy(); k += 2
+            scale = np.abs(gw).max() + 1e-12
+            np.testing.assert_allclose(lay.weight(q.arena.grad, n, l).cpu().numpy(), gw, rtol=1e-4, atol=2e-5 * scale)
+            np.testing.assert_allclose(lay.bias(q.arena.grad, n, l).cpu().numpy(), gb, rtol=1e-4, atol=2e-5 * scale)
+
+
+# --------------------------------------------------------------------------- losses
+def test_c51_projection_golden(golden, dev):
+    from pql_amd.utils.distl_util import projection
+    g = golden("math")
+    z = torch.linspace(-10, 10, 51, device=dev)
+    out = projection(T(g["proj_p"]).to(dev), T(g["proj_rew"]).to(dev), T(g["proj_done"]).to(dev), float(g["proj_gamma"]),
+                     -10, 10, 51, z, device=dev)
+    np.testing.assert_allclose(out.cpu().numpy(), g["proj_out"], atol=1e-7)
+    assert np.array_equal(out.cpu().numpy() != 0, g["proj_out"] != 0)   # same bins incl. integral-b / clamp / done rows
+    z2 = torch.linspace(-2, 6, 11, device=dev)
+    out2 = projection(T(g["proj2_p"]).to(dev), T(g["proj2_rew"]).to(dev), T(g["proj2_done"]).to(dev), 0.95, -2, 6, 11, z2)
+    np.testing.assert_allclose(out2.cpu().numpy(), g["proj2_out"], atol=1e-7)
+
+
+def _pad(x, ld):
+    out = torch.zeros((*x.shape[:-1], ld)); out[..., : x.shape[-1]] = x
+    return out
+
+
+@pytest.mark.parametrize("B", [64, 8192])
+def test_td_mse_loss(dev, ref, B):
+    from pql_amd import _lib as L
+    q = T(dd.uniform((2, B, 1), 81, -3, 3)); qt = T(dd.uniform((2, B, 1), 82, -3, 3))
+    rew = T(dd.uniform((B,), 83, -1, 1)); done = T(dd.bernoulli((B,), 84, 0.2)); gn = float(np.float32(0.99 ** 3))
+    qr = q.clone().requires_grad_(True)
+    y = rew.view(-1, 1) + (1 - done.view(-1, 1)) * gn * torch.min(qt[0], qt[1])
+    loss = torch.nn.functional.mse_loss(qr[0], y) + torch.nn.functional.mse_loss(qr[1], y)
+    loss.backward()
+    ld = 32
+    dy = torch.full((2, B, ld), 5.0, device=dev); lo = torch.zeros(1, device=dev); scr = torch.zeros(2048, device=dev)
+    L.check(L.lib.pqlk_td_mse_loss(L.ptr(_pad(q, ld).to(dev)), L.ptr(_pad(qt, ld).to(dev)), ld, L.ptr(rew.to(dev)),
+                                   L.ptr(done.to(dev)), gn, B, L.ptr(dy), L.ptr(lo), L.ptr(scr), L.stream(dev)))
+    np.testing.assert_allclose(lo.item(), loss.item(), rtol=2e-6)
+    np.testing.assert_allclose(dy[:, :, :1].cpu().numpy(), qr.grad.numpy(), rtol=1e-6, atol=1e-10)
+    assert torch.all(dy[:, :, 1:] == 0)
+
+
+@pytest.mark.parametrize("B", [37, 4096])
+def test_c51_bce_loss(dev, ref, B):
+    from pql_amd import _lib as L
+    K, ld = 51, 64
+    lg = T(dd.uniform((2, B, K), 91, -3, 3)); lt = T(dd.uniform((2, B, K), 92, -3, 3))
+    rew = T(dd.uniform((B, 1), 93, -2, 2)); done = T(dd.bernoulli((B, 1), 94, 0.2)); gn = float(np.float32(0.99 ** 3))
+    z = torch.linspace(-10, 10, K)
+    lr = lg.clone().requires_grad_(True)
+    with torch.no_grad():
+        tgt = torch.min(ref.c51_project_ref(torch.softmax(lt[0], 1), rew, done, gn, -10, 10, K),
+                        ref.c51_project_ref(torch.softmax(lt[1], 1), rew, done, gn, -10, 10, K))
+    F = torch.nn.functional
+    loss = F.binary_cross_entropy(torch.softmax(lr[0], 1), tgt) + F.binary_cross_entropy(torch.softmax(lr[1], 1), tgt)
+    loss.backward()
+    dy = torch.full((2, B, ld), 5.0, device=dev); lo = torch.zeros(1, device=dev); scr = torch.zeros(2048, device=dev)
+    pj = torch.empty((B, K), device=dev)
+    L.check(L.lib.pqlk_c51_bce_loss(L.ptr(_pad(lg, ld).to(dev)), L.ptr(_pad(lt, ld).to(dev)), ld, K, L.ptr(rew.view(-1).to(dev)),
+                                    L.ptr(done.view(-1).to(dev)), L.ptr(z.to(dev)), gn, -10.0, 10.0, B, L.ptr(dy), L.ptr(lo),
+                                    L.ptr(pj), L.ptr(scr), L.stream(dev)))
+    np.testing.assert_allclose(pj.cpu().numpy(), tgt.numpy(), atol=2e-7)
+    np.testing.assert_allclose(lo.item(), loss.item(), rtol=5e-6)
+    np.testing.assert_allclose(dy[:, :, :K].cpu().numpy(), lr.grad.numpy(), rtol=2e-4, atol=2e-9)
+    assert torch.all(dy[:, :, K:] == 0)
+
+
+@pytest.mark.parametrize("K", [1, 51])
+def test_dpg_loss(dev, K):
+    from pql_amd import _lib as L
+    B = 300; ld = L.ld(K)
+    q = T(dd.uniform((2, B, K), 95, -3, 3))
+    q[1, :5] = q[0, :5]  # ties -> gradient split evenly (torch.min backward)
+    z = torch.linspace(-10, 10, K) if K > 1 else None
+    qr = q.clone().requires_grad_(True)
+    if K == 1:
+        loss = -torch.min(qr[0], qr[1]).mean()
+    else:
+        e = [(torch.softmax(qr[i], 1) * z).sum(1) for i in range(2)]
+        loss = -torch.min(e[0], e[1]).mean()
+    loss.backward()
+    dy = torch.full((2, B, ld), 5.0, device=dev); lo = torch.zeros(1, device=dev); scr = torch.zeros(2048, device=dev)
+    L.check(L.lib.pqlk_dpg_loss(L.ptr(_pad(q, ld).to(dev)), ld, K, L.ptr(z.to(dev)) if K > 1 else None, B, L.ptr(dy), L.ptr(lo),
+                                L.ptr(scr), L.stream(dev)))
+    np.testing.assert_allclose(lo.item(), loss.item(), rtol=5e-6)
+    np.testing.assert_allclose(dy[:, :, :K].cpu().numpy(), qr.grad.numpy(), rtol=5e-5, atol=1e-9)
+    assert torch.all(dy[:, :, K:] == 0)
+
+
+# --------------------------------------------------------------------------- optimiser
+def test_clip_adamw_polyak_trace(dev, ref):
+    from pql_amd import _lib as L
+    n = 70016
+    p0 = T(dd.uniform((n,), 61, -0.1, 0.1)); t0 = T(dd.uniform((n,), 62, -0.1, 0.1))
+    opt = ref.AdamWRef([p0.clone()], lr=5e-4)
+    tgt = [t0.clone()]
+    p = p0.to(dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev); tg = t0.to(dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev); gn = torch.zeros(1, device=dev); scr = torch.zeros(2048, device=dev)
+    for s in range(4):
+        g = T(dd.uniform((n,), 63 + s, -1, 1)) * (10.0 if s % 2 == 0 else 1e-3)   # clipped and un-clipped steps
+        norm_ref = torch.linalg.vector_norm(g).item()
+        opt.apply([g.clone()], 0.5)
+        ref.polyak_ref(tgt, opt.params, 0.05)
+        gd = g.to(dev)
+        L.check(L.lib.pqlk_clip_adamw_polyak(L.ptr(p), L.ptr(gd), L.ptr(m), L.ptr(v), L.ptr(tg), n, 0.5, 5e-4, 0.9, 0.999,
+                                             1e-8, 1e-2, 0.05, L.ptr(step), L.ptr(gn), L.ptr(scr), L.stream(dev)))
+        np.testing.assert_allclose(gn.item(), norm_ref, rtol=1e-5)
+        np.testing.assert_allclose(p.cpu().numpy(), opt.params[0].numpy(), rtol=2e-6, atol=1e-8)
+        np.testing.assert_allclose(m.cpu().numpy(), opt.m[0].numpy(), rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(v.cpu().numpy(), opt.v[0].numpy(), rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(tg.cpu().numpy(), tgt[0].numpy(), rtol=2e-6, atol=1e-8)
+    assert step.item() == 4
+
+
+def test_batch_moments(dev):
+    from pql_amd.utils.torch_util import RunningMeanStd
+    x = T(dd.uniform((4096, 88), 55, -3, 5))
+    rms = RunningMeanStd(shape=(88,), device=dev)
+    bm, bv = rms.batch_moments(x.to(dev))
+    np.testing.assert_allclose(bm.cpu().numpy(), x.mean(0).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(bv.cpu().numpy(), x.var(0).numpy(), rtol=1e-5)
