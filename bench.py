@@ -1,0 +1,346 @@
+#!/usr/bin/env python3
+"""PQL learner throughput on MI355X: learner grad-steps/sec + env-steps/sec at 4096 envs, batch 8192.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One bench "step" = one slice of the PQL schedule at the reference's design ratios (pql_algo.yaml:17-18,
+train_pql.py:133,145): ONE V-learner gradient step on a batch of 8192, plus one P-learner gradient step every
+2nd step, plus one env iteration (4096 synthetic env steps -> running obs stats -> n-step assembly -> insert
+into the V and P replay rings -> weight hand-off) every 8th step.  So
+    value            = V-learner grad-steps/s (whole job)
+    p_grad_steps/s   = value / 2 ;  env_steps/s = value / 8 * num_envs
+Workload = BASELINE.json configs[1]: obs 88, act 16, replay 1M rows pre-filled to capacity and resident in HBM,
+DoubleQ MLP [512,512,256], n-step 3, synthetic transitions.
+
+N > 1: data-parallel weak scaling.  Every rank owns 4096 envs, a 1M-row replay shard and a batch of 8192; the
+only collective on the data path is the RCCL all-reduce of the flat gradient arena before the (replicated)
+optimiser step.  `value` then counts batch-8192 gradient steps summed over ranks (N x steps / time).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 2.4 GHz x 256 FLOP/clk
+PEAK_HBM_GBS = 8000.0
+
+TASKS = {"AllegroHand": (88, 16), "ShadowHand": (211, 20), "Humanoid": (108, 21), "Toy": (8, 2)}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=48)
+    ap.add_argument("--task", default="AllegroHand")
+    ap.add_argument("--num-envs", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=8192)
+    ap.add_argument("--replay", type=int, default=1_000_000)
+    ap.add_argument("--nstep", type=int, default=3)
+    ap.add_argument("--hidden", default="512,512,256", help="BASELINE shape; the reference default is 512,256,128")
+    ap.add_argument("--distl", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=24, help="V steps of the bounded CPU-oracle sample")
+    ap.add_argument("--v-only", action="store_true", help="time free-running V-learner steps only")
+    return ap.parse_args()
+
+
+def mlp_macs(dims):
+    return sum(a * b for a, b in zip(dims[:-1], dims[1:]))
+
+
+def flops_per_step(O, A, hidden, out_c, B):
+    """fwd = 2*MAC, bwd = 2 x fwd.  V-step = 2B(MAC_actor + 4*MAC_critic2); P = 2B(3 MAC_actor + 2 MAC_critic2)."""
+    mac_a = mlp_macs([O, *hidden, A])
+    mac_c2 = 2 * mlp_macs([O + A, *hidden, out_c])
+    return 2 * B * (mac_a + 4 * mac_c2), 2 * B * (3 * mac_a + 2 * mac_c2)
+
+
+def build_system(args, rank, world, device, pg):
+    from pql_amd.algo.pql_actor import PQLActor
+    from pql_amd.algo.pql_p_learner import PQLPLearner
+    from pql_amd.algo.pql_v_learner import PQLVLearner
+    from pql_amd.envs.synthetic import create_task_env
+    from pql_amd.utils.cfg import load_cfg
+    hidden = [int(x) for x in args.hidden.split(",")]
+    ov = [f"num_envs={args.num_envs}", f"task.name={args.task}", f"algo.batch_size={args.batch}",
+          f"algo.memory_size={args.replay}", f"algo.nstep={args.nstep}", f"algo.distl={args.distl}",
+          f"algo.v_learner_gpu={device.index}", f"algo.p_learner_gpu={device.index}", "algo.num_gpus=1",
+          f"algo.graph={not args.no_graph}", f"sim_device=cuda:{device.index}", f"device=cuda:{device.index}"]
+    cfg = load_cfg(ov)
+    cfg.algo.hidden_layers = hidden
+    cfg.algo.reward_scale = 0.01   # preprocess_cfg's AllegroHand value (common.py:159-170)
+    env = create_task_env(cfg, env_offset=rank * args.num_envs)
+    actor = PQLActor(env, cfg, env_offset=rank * args.num_envs, total_envs=world * args.num_envs)
+    v = PQLVLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=pg)
+    p = PQLPLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=pg)
+    if world > 1:   # replicated parameters: every rank starts from rank 0's weights
+        for t in (v.critic.arena.data, p.actor.arena.data):
+            torch.distributed.broadcast(t, src=0, group=pg)
+        v.critic_target.arena.data.copy_(v.critic.arena.data)
+        actor.obs_rms.pg = pg
+    return cfg, env, actor, v, p
+
+
+def prefill(actor, v, p, env, cfg, args, device):
+    """Warm-up rollout (train_pql.py:57-68), then fill both replay rings to capacity with synthetic rows so the
+    randint bound is constant and samples come from HBM, not cache."""
+    critic, _, _ = v.start()
+    pol, _, _ = p.start()
+    from copy import deepcopy
+    actor.actor = deepcopy(pol)
+    actor.reset_agent()
+    p_data, v_data, _ = actor.explore_env(env, cfg.algo.warm_up, random=True)
+    v.update(pol, v_data, actor.obs_rms.get_states(device), 0)
+    p.update(critic, p_data, actor.obs_rms.get_states(device), 0)
+    O, A = env.obs_dim, env.act_dim
+    chunk = 65536
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 + device.index)
+    while not v.memory.if_full:
+        m = min(chunk, v.memory.capacity)
+        obs = torch.randn((m, O), device=device, generator=g)
+        traj = (obs, torch.rand((m, A), device=device, generator=g) * 2 - 1, torch.randn((m, 1), device=device, generator=g) * 0.01,
+                torch.randn((m, O), device=device, generator=g), (torch.rand((m, 1), device=device, generator=g) < 1 / 300).float())
+        v.update(pol, traj, actor.obs_rms.get_states(device), 0)
+        p.update(critic, obs, actor.obs_rms.get_states(device), 0)
+    torch.cuda.synchronize(device)
+
+
+class Schedule:
+    """The 1 : 2 : 8 slice schedule (env : P : V)."""
+
+    def __init__(self, actor, v, p, env, cfg, device, v_only=False):
+        self.actor, self.v, self.p, self.env, self.cfg, self.device, self.v_only = actor, v, p, env, cfg, device, v_only
+        self.k = 0
+        self.r_p = int(cfg.algo.critic_actor_ratio)
+        self.r_env = int(cfg.algo.critic_sample_ratio)
+        self.global_steps = 0
+
+    def step(self):
+        k = self.k
+        self.k += 1
+        if not self.v_only and k % self.r_env == 0:
+            p_data, v_data, n = self.actor.explore_env(self.env, self.cfg.algo.horizon_len, random=False)
+            self.global_steps += n
+            rms = self.actor.obs_rms.get_states(self.device)
+            self.v.update(self.actor.actor, v_data, rms, 0)      # transitions + policy replica -> V-learner
+            self.p.update(self.v.critic, p_data, rms, 0)         # obs + critic replica -> P-learner
+            self.actor.actor.arena.data.copy_(self.p.actor.arena.data)   # newest policy -> rollout
+        self.v.learn()
+        if not self.v_only and k % self.r_p == self.r_p - 1:
+            self.p.learn()
+
+
+def gemm_section_ms(v, iters=20):
+    """Device time of the fp32-MFMA GEMM launches of ONE V-learner step (actor fwd + target twin fwd + twin fwd +
+    twin bwd), measured with HIP events on the stream they are launched on (torch's current stream)."""
+    from pql_amd import _lib as L
+    import ctypes as C
+    ws = v._workspace(int(v.cfg.algo.batch_size))
+    B = ws["B"]
+    al, cl = v.actor.layout, v.critic.layout
+    st = lambda: L.stream(v.device)  # noqa: E731
+    O = v.memory.ring.O
+
+    def section():
+        L.check(L.lib.pqlk_mlp_forward(C.byref(al.desc), L.ptr(v.actor.arena.data), L.ptr(ws["xn_obs"]), ws["ld_o"], B,
+                                       L.ACT_TANH_NOISE, L.ptr(ws["draw"]), 0.8, 0.2, L.ptr(ws["acts_a"]),
+                                       L.ptr(ws["xn_sa"][:, O:]), ws["ld_sa"], st()))
+        L.check(L.lib.pqlk_mlp_forward(C.byref(cl.desc), L.ptr(v.critic_target.arena.data), L.ptr(ws["xn_sa"]), ws["ld_sa"], B,
+                                       L.ACT_NONE, None, 0.0, 0.0, L.ptr(ws["acts_t"]), None, 0, st()))
+        L.check(L.lib.pqlk_mlp_forward(C.byref(cl.desc), L.ptr(v.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
+                                       L.ACT_NONE, None, 0.0, 0.0, L.ptr(ws["acts_c"]), None, 0, st()))
+        L.check(L.lib.pqlk_mlp_backward(C.byref(cl.desc), L.ptr(v.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
+                                        L.ptr(ws["acts_c"]), L.ptr(ws["dy"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0, 0,
+                                        None, 0, L.ptr(ws["bwd"]), ws["bwd"].numel(), st()))
+
+    with torch.cuda.device(v.device):
+        for _ in range(3):
+            section()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            section()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+
+def gather_ms(v, iters=50):
+    """Device time of one fused replay gather launch (HIP events, same stream)."""
+    from pql_amd import _lib as L
+    import ctypes as C
+    ws = v._workspace(int(v.cfg.algo.batch_size))
+    B = ws["B"]
+    mean, var, eps = v._norm_ptrs()
+    idx = torch.randint(v.memory.cur_capacity, size=(iters + 3, B), device=v.device)
+
+    def one(i):
+        L.check(L.lib.pqlk_replay_gather_fused(C.byref(v.memory.ring.desc), L.ptr(idx[i]), B, L.ptr(mean), L.ptr(var), eps, 1,
+                                               L.ptr(ws["x_sa"]), ws["ld_sa"], L.ptr(ws["xn_sa"]), L.ptr(ws["xn_obs"]), ws["ld_o"],
+                                               L.ptr(ws["rew"]), L.ptr(ws["done"]), L.stream(v.device)))
+    with torch.cuda.device(v.device):
+        for i in range(3):
+            one(i)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(iters):
+            one(3 + i)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+
+def cpu_baseline(args, O, A, hidden):
+    """The CPU oracle (port of the reference learner, pinned to the reference by tests/golden) on this host's
+    cores, same schedule, bounded sample."""
+    import numpy as np
+    from oracle import pql_ref_cpu as ref
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    B, N, cap = args.batch, args.num_envs, min(args.replay, 200_000)   # smaller resident ring: CPU RAM/time bound
+    g = torch.Generator().manual_seed(0)
+    dims_a = ref.layer_dims(O, A, hidden)
+    dims_c = ref.layer_dims(O + A, 51 if args.distl else 1, hidden)
+
+    def init(dims):
+        out = []
+        for fi, fo in dims:
+            bnd = 1.0 / np.sqrt(fi)
+            out += [(torch.rand((fo, fi), generator=g) * 2 - 1) * bnd, (torch.rand((fo,), generator=g) * 2 - 1) * bnd]
+        return out
+
+    hp = ref.HyperRef(batch_size=B, distl=args.distl, nstep=args.nstep)
+    apar = init(dims_a)
+    v = ref.VLearnerRef(O, A, hp, cap, init(dims_c), init(dims_c))
+    p = ref.PLearnerRef(O, A, hp, cap, apar)
+    ns = ref.NStepRef(O, A, N, args.nstep)
+    rms = ref.RunningMeanStdRef((O,))
+    rows = cap
+    data = (torch.randn((rows, O), generator=g), torch.rand((rows, A), generator=g) * 2 - 1, torch.randn((rows, 1), generator=g) * .01,
+            torch.randn((rows, O), generator=g), (torch.rand((rows, 1), generator=g) < 1 / 300).float())
+    rms.update(data[0])
+    v.update(apar, data, rms.states())
+    p.update(v.q1, v.q2, data[0], rms.states())
+    warm = [torch.randn((N, args.nstep, O), generator=g), torch.rand((N, args.nstep, A), generator=g), torch.randn((N, args.nstep, 1), generator=g),
+            torch.randn((N, args.nstep, O), generator=g), torch.zeros((N, args.nstep, 1))]
+    ns.add(*warm)
+
+    def step(k):
+        if k % 8 == 0:
+            obs = torch.randn((N, 1, O), generator=g)
+            rms.update(obs[:, 0])
+            act = ref.mixed_noise_ref(ref.actor_forward_ref([q.detach() for q in p.actor], ref.normalize_ref(obs[:, 0], rms.states(), clamp=False)),
+                                      torch.randn((N, A), generator=g), 0.05, 0.8)
+            out = ns.add(obs, act.unsqueeze(1), torch.randn((N, 1, 1), generator=g) * 0.01, torch.randn((N, 1, O), generator=g),
+                         (torch.rand((N, 1, 1), generator=g) < 1 / 300).float())
+            v.update([q.detach() for q in p.actor], out, rms.states())
+            p.update(v.q1, v.q2, out[0], rms.states())
+        v.learn(generator=g)
+        if k % 2 == 1:
+            p.learn(generator=g)
+
+    for k in range(4):
+        step(k)
+    t0 = time.perf_counter()
+    for k in range(args.cpu_steps):
+        step(k)
+    dt = time.perf_counter() - t0
+    return {"value": args.cpu_steps / dt, "unit": "V-learner grad-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_steps} schedule steps (1 V + 1/2 P + 1/8 env iteration each) of oracle/pql_ref_cpu.py, "
+                      f"batch {B}, hidden {list(hidden)}, replay {cap} rows, torch {torch.__version__} CPU, {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    device = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(device)
+    pg = None
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=device)   # RCCL
+        pg = torch.distributed.group.WORLD
+    torch.manual_seed(42 + rank)
+
+    cfg, env, actor, v, p = build_system(args, rank, world, device, pg)
+    prefill(actor, v, p, env, cfg, args, device)
+    sched = Schedule(actor, v, p, env, cfg, device, v_only=args.v_only)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier(group=pg)
+
+    for _ in range(args.warmup):
+        sched.step()
+    barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sched.step()
+    torch.cuda.synchronize(device)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX, group=pg)
+        dt = float(tt.item())
+
+    hidden = [int(x) for x in args.hidden.split(",")]
+    O, A = env.obs_dim, env.act_dim
+    out_c = 51 if args.distl else 1
+    f_v, f_p = flops_per_step(O, A, hidden, out_c, args.batch)
+    value = world * args.steps / dt
+    line = {
+        "metric": "learner grad-steps/sec + env-steps/sec, 4096 envs batch 8192 (value = V-learner grad-steps/s at the 1:2:8 "
+                  "env:P:V schedule; batch-8192 steps summed over ranks)",
+        "value": value, "unit": "V-learner grad-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"PQL 1xMI355X cfg#2: {args.num_envs} synthetic envs ({args.task}-shape obs={O} act={A}), replay "
+                               f"{args.replay} rows resident in HBM, batch {args.batch}, n-step {args.nstep}, "
+                               f"{'DistributionalDoubleQ(51)' if args.distl else 'DoubleQ'} MLP {hidden}",
+                   "schedule": "v_only" if args.v_only else "1 env-iteration : 4 P-steps : 8 V-steps",
+                   "graph": not args.no_graph, "parallelism": f"dp{world}" if world > 1 else "single"},
+        "p_grad_steps_per_s": 0.0 if args.v_only else value / int(cfg.algo.critic_actor_ratio),
+        "env_steps_per_s": 0.0 if args.v_only else value / int(cfg.algo.critic_sample_ratio) * args.num_envs,
+        "gflop_per_v_step": f_v / 1e9, "gflop_per_p_step": f_p / 1e9,
+    }
+    if rank == 0:
+        # roofline of the dominant kernel family: the fp32-MFMA GEMMs of one V step (k_gemm<...>)
+        ms = gemm_section_ms(v)
+        achieved = f_v / (ms * 1e-3) / 1e12
+        line["roofline"] = {"bound": "mfma", "kernel": "k_gemm (all fp32 v_mfma_f32_32x32x2 GEMM launches of one V-learner step)",
+                            "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "ms_per_launch_group": ms}
+        gms = gather_ms(v)
+        rec_ld = v.memory.ring.rec_ld
+        alg_bytes = args.batch * ((2 * O + A) * 4 + 4 + 1 + 8 + (2 * O + A) * 4 + 4 + 4)   # 1557 B/sample @cfg2
+        line["roofline_gather"] = {"bound": "hbm", "kernel": "k_replay_gather_fused", "achieved": alg_bytes / (gms * 1e-3) / 1e9,
+                                   "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_bytes / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                   "traffic": None, "us_per_launch": gms * 1e3, "record_bytes": rec_ld * 4}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args, O, A, hidden)
+            line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -179,14 +179,18 @@ int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const float* x, 
                       float* ws, int64_t ws_floats, pqlk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Losses.  Each writes dy (2, B, ld) for pqlk_mlp_backward and one scalar loss into loss_out[0]
- * (device), via per-block partials in `scratch` (>= 1024 floats) reduced in fixed order.
+ * Losses.  Each writes dy (2, B, ld) for pqlk_mlp_backward and one scalar loss (device), via per-block
+ * partials in `scratch` (>= 1024 floats) reduced in fixed order.  The scalar lands in
+ * loss_out[slot_dev[0] % ring_len] when slot_dev != NULL (a device int32 counter, normally the optimiser's
+ * step counter: gives a graph-replay-safe ring of the last `ring_len` losses, replacing the reference's
+ * per-step `.item()` host sync, pql_v_learner.py:111), else in loss_out[0].
  * ---------------------------------------------------------------------------------------------- */
 
 /* TD target + twin MSE (pql_v_learner.py:104-108): y = r + (1-d) * gamma_n * min(qt1, qt2);
  * loss = mean((q1-y)^2) + mean((q2-y)^2).  q, qt: (2, B, ld) with the value in column 0. */
 int pqlk_td_mse_loss(const float* q, const float* qt, int64_t ld, const float* rew, const float* done,
-                     float gamma_n, int64_t b, float* dy, float* loss_out, float* scratch, pqlk_stream_t stream);
+                     float gamma_n, int64_t b, float* dy, float* loss_out, const int32_t* slot_dev, int32_t ring_len,
+                     float* scratch, pqlk_stream_t stream);
 
 /* C51: softmax of target logits, categorical projection x2 (pql/utils/distl_util.py:4-20), elementwise
  * min (pql_v_learner.py:83-102), softmax of current logits, twin BCE (mean over B*K, log clamped at
@@ -195,8 +199,8 @@ int pqlk_td_mse_loss(const float* q, const float* qt, int64_t ld, const float* r
  * If proj_out != NULL the (B, K) target pmf is also stored (tests). */
 int pqlk_c51_bce_loss(const float* logits, const float* logits_t, int64_t ld, int32_t k,
                       const float* rew, const float* done, const float* support /*(K) z atoms*/, float gamma_n,
-                      float v_min, float v_max, int64_t b, float* dy, float* loss_out, float* proj_out,
-                      float* scratch, pqlk_stream_t stream);
+                      float v_min, float v_max, int64_t b, float* dy, float* loss_out, const int32_t* slot_dev,
+                      int32_t ring_len, float* proj_out, float* scratch, pqlk_stream_t stream);
 
 /* Stand-alone projection = projection() of distl_util.py:4-20 on a given pmf (B, K) contiguous. */
 int pqlk_c51_project(const float* p, const float* rew, const float* done, const float* support, float gamma_n,
@@ -206,11 +210,13 @@ int pqlk_c51_project(const float* p, const float* rew, const float* done, const 
  * torch.min's backward).  k == 1: q (2,B,ld) scalar heads.  k > 1: logits of the distributional critic,
  * Q_i = sum softmax(logits_i) * z (mlp.py:256-260), dy = gradient w.r.t. the logits. */
 int pqlk_dpg_loss(const float* q, int64_t ld, int32_t k, const float* support /*(K), NULL when k == 1*/, int64_t b,
-                  float* dy, float* loss_out, float* scratch, pqlk_stream_t stream);
+                  float* dy, float* loss_out, const int32_t* slot_dev, int32_t ring_len, float* scratch,
+                  pqlk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Optimiser: clip_grad_norm_ + AdamW (+ Polyak) over flat arenas
  * (pql_v_learner.py:124-133, pql_p_learner.py:87-96, pql/utils/torch_util.py:9-12).
+ *   g *= grad_scale   (1/world_size after a data-parallel sum all-reduce; 1.0 otherwise)
  *   total = ||g||_2 ; g *= min(1, max_norm / (total + 1e-6))   (max_norm <= 0 disables clipping)
  *   p *= 1 - lr*wd ; m += (g-m)(1-b1) ; v = b2 v + (1-b2) g^2
  *   p -= (lr / (1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
@@ -218,7 +224,7 @@ int pqlk_dpg_loss(const float* q, int64_t ld, int32_t k, const float* support /*
  * step_dev: device int32 counter t, incremented by the call (graph-replay safe).
  * scratch: >= 2048 floats.  gnorm_out (device, may be NULL) receives the pre-clip norm.
  * ---------------------------------------------------------------------------------------------- */
-int pqlk_clip_adamw_polyak(float* p, float* g, float* m, float* v, float* target, int64_t n,
+int pqlk_clip_adamw_polyak(float* p, float* g, float* m, float* v, float* target, int64_t n, float grad_scale,
                            float max_norm, float lr, float b1, float b2, float eps, float wd, float tau,
                            int32_t* step_dev, float* gnorm_out, float* scratch, pqlk_stream_t stream);
 

@@ -174,7 +174,11 @@ def normalize_ref(x, norm: Optional[Tuple[torch.Tensor, torch.Tensor, float]], c
     if norm is None:
         return x
     mean, var, eps = norm
-    y = (x - mean.float()) / torch.sqrt(var.float() + eps)
+    # sqrt through numpy: IEEE correctly rounded on every host.  torch's vectorised CPU sqrt is not
+    # (about 0.6 % of inputs are 1 ulp off on some ISAs), which would make this oracle host-dependent;
+    # the GPU's sqrtf and '/' are correctly rounded (tools/probes/probe_fp.hip).
+    std = torch.from_numpy(np.sqrt((var.float() + eps).numpy()))
+    y = (x - mean.float()) / std
     return y.clamp(-5.0, 5.0) if clamp else y
 
 

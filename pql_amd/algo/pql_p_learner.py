@@ -1,0 +1,209 @@
+"""P-learner: the policy side of Parallel Q-Learning on one MI355X.
+
+Drop-in for `pql/algo/pql_p_learner.py`: `PQLPLearner(obs_dim, action_dim, cfg)` with `start()`, `learn()`,
+`update(critic, obs, normalize_tuple, sleep_time)` and the pump `asyn_p_learner`.
+
+learn()  (reference :47-64)  ->  one launch sequence
+    randint -> fused obs gather+normalise -> actor fwd (tanh; action dropped into the critic input) ->
+    frozen twin-critic fwd -> DPG loss -mean(min Q) + dL/dQ -> critic bwd, dX ONLY, both nets summed in
+    one GEMM, chained through tanh' in the epilogue -> actor bwd (dW + dX) -> clip + AdamW.
+`critic.requires_grad_(False)` of the reference (:54) is structural here: no dW GEMM is launched for the critic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from copy import deepcopy
+
+import torch
+
+from pql_amd import _lib as L
+from pql_amd.algo.pql_v_learner import LOSS_RING, _AdamState, _cfg_get, apply_optimizer, resident_norm
+from pql_amd.models import model_name_to_path
+from pql_amd.models.mlp import default_splits, output_view
+from pql_amd.replay.simple_replay import RecordRing, _obs_width, ring_plan
+from pql_amd.utils.common import Tracker, load_class_from_path
+
+
+class PQLPLearner:
+    def __init__(self, obs_dim, action_dim, cfg, process_group=None):
+        self.cfg = cfg
+        self.obs_dim = obs_dim
+        self.action_dim = int(action_dim)
+        if not torch.cuda.is_available():
+            raise L.PqlkError("PQLPLearner needs an MI355X (no CPU path)")
+        self.device = torch.device(f"cuda:{int(cfg.algo.p_learner_gpu)}")
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        algo = cfg.algo
+        act_class = load_class_from_path(algo.act_class, model_name_to_path[algo.act_class])
+        hidden = _cfg_get(algo, "hidden_layers")
+        hidden = list(hidden) if hidden is not None else None
+        with torch.cuda.device(self.device):
+            self.actor = act_class(self.obs_dim, self.action_dim, hidden_layers=hidden).to(self.device)
+        if cfg.artifact is not None:
+            raise NotImplementedError("W&B artifact download is out of scope (no network); load a local state_dict instead")
+        self.opt = _AdamState(self.actor.arena.data)
+        self.critic = None
+
+        # obs-only replay (reference :32-37: a bare (memory_size, obs) tensor + inline pointer logic)
+        self.memory_size = int(algo.memory_size)
+        self.ring = RecordRing(self.memory_size, _obs_width(obs_dim), -1, self.device)
+        self.next_p = 0
+        self.if_full = False
+        self.cur_capacity = 0
+
+        self.loss_tracker = Tracker(LOSS_RING)
+        self.loss_ring = torch.zeros(LOSS_RING, dtype=torch.float32, device=self.device)
+        self.update_count = 0
+        self.normalize_tuple = None
+        self.sleep_time = 0.01
+        self.use_graph = bool(_cfg_get(algo, "graph", False))
+        self._ws = None
+        self._graph = None
+        self._graph_key = None
+
+    @property
+    def memory(self):
+        """(memory_size, obs_dim) view of the ring, the reference's attribute name (:34)."""
+        return self.ring.records[:, : self.ring.O]
+
+    def start(self):
+        return self.actor, self.update_count, self.loss_tracker.mean()
+
+    def _workspace(self, B):
+        if self._ws is not None and self._ws["B"] == B:
+            return self._ws
+        f = dict(dtype=torch.float32, device=self.device)
+        O, A = self.ring.O, self.action_dim
+        al, cl = self.actor.layout, self.critic.layout
+        ws = dict(B=B, ld_sa=L.ld(O + A), ld_o=L.ld(O), ld_a=L.ld(A))
+        ws["x_sa"] = torch.zeros((B, ws["ld_sa"]), **f)
+        ws["x_obs"] = torch.zeros((B, ws["ld_o"]), **f)
+        ws["idx"] = torch.zeros(B, dtype=torch.int64, device=self.device)
+        ws["acts_a"] = torch.empty(al.acts_floats(B), **f)
+        ws["acts_c"] = torch.empty(cl.acts_floats(B), **f)
+        ws["dy_c"] = torch.zeros((2, B, cl.ld_out), **f)
+        ws["dz_a"] = torch.zeros((1, B, ws["ld_a"]), **f)   # dL/d(actor pre-tanh); pad columns stay zero
+        ws["grads"] = torch.zeros(al.total, **f)
+        ws["splits"] = default_splits(B)
+        ws["bwd_c"] = torch.empty(cl.bwd_ws_floats(B, 1), **f)
+        ws["bwd_a"] = torch.empty(al.bwd_ws_floats(B, ws["splits"]), **f)
+        ws["scratch"] = torch.zeros(2048, **f)
+        self._ws = ws
+        return ws
+
+    def _step_kernels(self, ws, idx):
+        algo, dev, B = self.cfg.algo, self.device, ws["B"]
+        O, A = self.ring.O, self.action_dim
+        st = L.stream(dev)
+        mean, var, eps = (None, None, 0.0)
+        if algo.obs_norm and self.normalize_tuple is not None:
+            mean, var, eps = self.normalize_tuple
+        L.check(L.lib.pqlk_replay_gather_fused(C.byref(self.ring.desc), L.ptr(idx), B, L.ptr(mean), L.ptr(var), float(eps), 1,
+                                               L.ptr(ws["x_sa"]), ws["ld_sa"], None, L.ptr(ws["x_obs"]), ws["ld_o"], None, None,
+                                               st))
+        al, cl = self.actor.layout, self.critic.layout
+        x_act = ws["x_sa"][:, O:]
+        L.check(L.lib.pqlk_mlp_forward(C.byref(al.desc), L.ptr(self.actor.arena.data), L.ptr(ws["x_obs"]), ws["ld_o"], B,
+                                       L.ACT_TANH, None, 0.0, 0.0, L.ptr(ws["acts_a"]), L.ptr(x_act), ws["ld_sa"], st))
+        L.check(L.lib.pqlk_mlp_forward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
+                                       L.ACT_NONE, None, 0.0, 0.0, L.ptr(ws["acts_c"]), None, 0, st))
+        q = output_view(cl, ws["acts_c"], B)
+        K = int(getattr(self.critic, "num_atoms", 1))
+        z = getattr(self.critic, "z_atoms", None) if K > 1 else None
+        L.check(L.lib.pqlk_dpg_loss(L.ptr(q), cl.ld_out, K, L.ptr(z), B, L.ptr(ws["dy_c"]), L.ptr(self.loss_ring),
+                                    L.ptr(self.opt.step), LOSS_RING, L.ptr(ws["scratch"]), st))
+        a_out = output_view(al, ws["acts_a"], B)  # (1, B, ld_a): tanh output, for the tanh' chain
+        L.check(L.lib.pqlk_mlp_backward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
+                                        L.ptr(ws["acts_c"]), L.ptr(ws["dy_c"]), None, 1, L.ptr(ws["dz_a"]), ws["ld_a"], O, A,
+                                        L.ptr(a_out), ws["ld_a"], L.ptr(ws["bwd_c"]), ws["bwd_c"].numel(), st))
+        L.check(L.lib.pqlk_mlp_backward(C.byref(al.desc), L.ptr(self.actor.arena.data), L.ptr(ws["x_obs"]), ws["ld_o"], B,
+                                        L.ptr(ws["acts_a"]), L.ptr(ws["dz_a"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0, 0,
+                                        None, 0, L.ptr(ws["bwd_a"]), ws["bwd_a"].numel(), st))
+        if self.world > 1:
+            torch.distributed.all_reduce(ws["grads"], group=self.pg)
+        apply_optimizer(self.actor.arena.data, ws["grads"], self.opt, None, algo.actor_lr, algo.max_grad_norm, 0.0,
+                        1.0 / self.world, dev)
+
+    def _draw_and_step(self, ws):
+        ws["idx"].copy_(torch.randint(self.cur_capacity, size=(ws["B"],), device=self.device))  # the only draw (:49)
+        self._step_kernels(ws, ws["idx"])
+
+    @torch.no_grad()
+    def learn(self, indices=None):
+        if self.critic is None:
+            return self.sleep_time
+        B = int(self.cfg.algo.batch_size)
+        with torch.cuda.device(self.device):
+            ws = self._workspace(B)
+            if indices is not None:
+                self._step_kernels(ws, indices.to(self.device, torch.int64).contiguous())
+            elif self.use_graph:
+                key = (B, self.cur_capacity, id(self.critic), self.normalize_tuple is None)
+                if self._graph is None or self._graph_key != key:
+                    self._capture(ws, key)
+                self._graph.replay()
+            else:
+                self._draw_and_step(ws)
+        self.update_count += 1
+        return self.sleep_time
+
+    def _state(self):
+        return (self.actor.arena.data, self.opt.m, self.opt.v, self.opt.step, self.loss_ring)
+
+    def _capture(self, ws, key):
+        snap = [t.clone() for t in self._state()]
+        rng = torch.cuda.get_rng_state(self.device)
+        s = torch.cuda.Stream(self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            self._draw_and_step(ws)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        for dst, src in zip(self._state(), snap):
+            dst.copy_(src)
+        torch.cuda.set_rng_state(rng, self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._draw_and_step(ws)
+        torch.cuda.set_rng_state(rng, self.device)
+        self._graph, self._graph_key = g, key
+
+    def loss_mean(self):
+        vals = self.loss_ring.tolist()
+        n = min(self.update_count, LOSS_RING)
+        self.loss_tracker = Tracker(LOSS_RING)
+        for t in range(self.update_count - n, self.update_count):
+            self.loss_tracker.update(vals[t % LOSS_RING])
+        return self.loss_tracker.mean()
+
+    def set_critic(self, critic):
+        """Adopt new critic weights into a resident replica (flat arena copy; peer copy over xGMI when the
+        V-learner lives on another GPU) -- the reference pickles the whole module through Ray instead."""
+        if self.critic is None or self.critic.layout.dims != critic.layout.dims:
+            self.critic = deepcopy(critic).to(self.device)
+            if hasattr(self.critic, "z_atoms"):
+                self.critic.z_atoms = self.critic.z_atoms.to(self.device)
+                self.critic.device = self.device
+        elif critic is not self.critic:
+            self.critic.arena.data.copy_(critic.arena.data, non_blocking=True)
+
+    @torch.no_grad()
+    def update(self, critic, obs, normalize_tuple, sleep_time):
+        self.set_critic(critic)
+        self.sleep_time = sleep_time
+        self.normalize_tuple = resident_norm(self, normalize_tuple)
+        obs = obs.reshape(-1, self.ring.O).to(self.device, torch.float32).contiguous()
+        self.add_capacity = obs.shape[0]
+        segs, self.next_p, self.if_full, self.cur_capacity = ring_plan(self.next_p, self.if_full, self.memory_size,
+                                                                       obs.shape[0])
+        self.ring.insert_segments(segs, obs)
+        return self.actor, self.loss_mean(), self.update_count
+
+
+def asyn_p_learner(learner, cfg, stop_event=None):
+    """Free-running pump (reference: a Ray task, :99-104).  Run it in a thread."""
+    while stop_event is None or not stop_event.is_set():
+        sleep_time = learner.learn()
+        if sleep_time:
+            time.sleep(sleep_time)

@@ -1,0 +1,285 @@
+"""V-learner: the critic side of Parallel Q-Learning on one MI355X.
+
+Drop-in for `pql/algo/pql_v_learner.py`: `PQLVLearner(obs_dim, action_dim, cfg)` with `start()`,
+`learn()`, `update(actor, trajectory, normalize_tuple, sleep_time)` and the module-level pump
+`asyn_v_learner(learner, cfg)`.  The reference wraps the class in a Ray actor (:21) and ships whole
+nn.Modules through the object store; here it is a plain object that owns a HIP stream's worth of work:
+
+learn()  (reference :73-115, ~150 ATen launches + 1 host sync)  ->  one fixed launch sequence
+    randint -> fused gather+normalise+cat -> actor fwd (+target-policy noise, written straight into the
+    target critic's input) -> target twin-critic fwd -> twin-critic fwd -> TD/MSE or C51/BCE loss + dL/dQ
+    -> critic bwd (split-batch dW) -> clip + AdamW + Polyak over flat arenas.
+No `.item()`: losses land in a device ring read lazily by `update()`.  With `cfg.algo.graph` the sequence
+is captured once into a hipGraph (through torch.cuda.CUDAGraph) and replayed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from copy import deepcopy
+
+import torch
+
+from pql_amd import _lib as L
+from pql_amd.models import model_name_to_path
+from pql_amd.models.mlp import default_splits, output_view
+from pql_amd.replay.simple_replay import ReplayBuffer
+from pql_amd.utils.common import Tracker, load_class_from_path
+
+LOSS_RING = 5  # Tracker(5) of the reference (:54)
+
+
+def _cfg_get(node, name, default=None):
+    try:
+        v = getattr(node, name)
+    except (AttributeError, KeyError):
+        return default
+    return default if v is None else v
+
+
+class _AdamState:
+    """m, v, step counter and scratch for one parameter arena."""
+
+    def __init__(self, arena: torch.Tensor):
+        self.m = torch.zeros_like(arena)
+        self.v = torch.zeros_like(arena)
+        self.step = torch.zeros(1, dtype=torch.int32, device=arena.device)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=arena.device)
+        self.scratch = torch.zeros(2048, dtype=torch.float32, device=arena.device)
+
+
+def apply_optimizer(arena, grads, st: _AdamState, target, lr, max_grad_norm, tau, grad_scale=1.0, device=None):
+    """clip_grad_norm_ + AdamW(torch defaults: betas .9/.999, eps 1e-8, wd 1e-2) + optional Polyak."""
+    L.check(L.lib.pqlk_clip_adamw_polyak(L.ptr(arena), L.ptr(grads), L.ptr(st.m), L.ptr(st.v), L.ptr(target),
+                                         arena.numel(), float(grad_scale),
+                                         float(max_grad_norm) if max_grad_norm is not None else 0.0,
+                                         float(lr), 0.9, 0.999, 1e-8, 1e-2, float(tau), L.ptr(st.step), L.ptr(st.gnorm),
+                                         L.ptr(st.scratch), L.stream(device)))
+
+
+def resident_norm(owner, normalize_tuple):
+    """Copy (mean, var, eps) into buffers that live as long as the learner, so kernels (and captured
+    graphs) always read the same addresses; the producer may hand over fresh tensors every iteration."""
+    if normalize_tuple is None:
+        return None
+    mean, var, eps = normalize_tuple
+    cur = getattr(owner, "_norm_buf", None)
+    if cur is None or cur[0].shape != mean.reshape(-1).shape:
+        cur = (torch.empty(mean.numel(), dtype=torch.float32, device=owner.device),
+               torch.empty(var.numel(), dtype=torch.float32, device=owner.device))
+        owner._norm_buf = cur
+    cur[0].copy_(mean.reshape(-1), non_blocking=True)
+    cur[1].copy_(var.reshape(-1), non_blocking=True)
+    return cur[0], cur[1], float(eps)
+
+
+class PQLVLearner:
+    def __init__(self, obs_dim, action_dim, cfg, process_group=None):
+        self.cfg = cfg
+        self.obs_dim = obs_dim
+        self.action_dim = int(action_dim)
+        if not torch.cuda.is_available():
+            raise L.PqlkError("PQLVLearner needs an MI355X (no CPU path)")
+        self.device = torch.device(f"cuda:{int(cfg.algo.v_learner_gpu)}")
+        self.pg = process_group  # data-parallel group (RCCL); None = single GPU
+        self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+
+        algo = cfg.algo
+        if algo.distl and "Distributional" not in algo.cri_class:
+            algo.cri_class = "Distributional" + algo.cri_class  # same rewrite as the reference (:30-31)
+        cri_class = load_class_from_path(algo.cri_class, model_name_to_path[algo.cri_class])
+        hidden = _cfg_get(algo, "hidden_layers")
+        hidden = list(hidden) if hidden is not None else None
+        with torch.cuda.device(self.device):
+            if algo.distl:
+                self.critic = cri_class(self.obs_dim, self.action_dim, v_min=algo.v_min, v_max=algo.v_max,
+                                        num_atoms=algo.num_atoms, device=self.device, hidden_layers=hidden).to(self.device)
+            else:
+                self.critic = cri_class(self.obs_dim, self.action_dim, hidden_layers=hidden).to(self.device)
+        if cfg.artifact is not None:
+            raise NotImplementedError("W&B artifact download is out of scope (no network); load a local state_dict instead")
+        self.critic_target = deepcopy(self.critic)
+        self.opt = _AdamState(self.critic.arena.data)
+        self.actor = None
+        self.memory = ReplayBuffer(capacity=int(algo.memory_size), obs_dim=self.obs_dim, action_dim=self.action_dim,
+                                   device=self.device)
+        self.loss_tracker = Tracker(LOSS_RING)
+        self.loss_ring = torch.zeros(LOSS_RING, dtype=torch.float32, device=self.device)
+        self.update_count = 0
+        self.normalize_tuple = None
+        self.sleep_time = 0
+        self.use_graph = bool(_cfg_get(algo, "graph", False))
+        self._ws = None
+        self._graph = None
+        self._graph_key = None
+
+    # ------------------------------------------------------------------------------------------
+    def start(self):
+        return self.critic, self.update_count, self.loss_tracker.mean()
+
+    def _workspace(self, B):
+        if self._ws is not None and self._ws["B"] == B:
+            return self._ws
+        dev, f = self.device, dict(dtype=torch.float32, device=self.device)
+        O, A = self.memory.ring.O, self.action_dim
+        cl, al = self.critic.layout, self.actor.layout
+        ws = dict(B=B, ld_sa=L.ld(O + A), ld_o=L.ld(O))
+        ws["x_sa"] = torch.zeros((B, ws["ld_sa"]), **f)
+        ws["xn_sa"] = torch.zeros((B, ws["ld_sa"]), **f)
+        ws["xn_obs"] = torch.zeros((B, ws["ld_o"]), **f)
+        ws["rew"] = torch.zeros(B, **f)
+        ws["done"] = torch.zeros(B, **f)
+        ws["idx"] = torch.zeros(B, dtype=torch.int64, device=dev)
+        ws["draw"] = torch.zeros((B, A), **f)
+        ws["acts_a"] = torch.empty(al.acts_floats(B), **f)
+        ws["acts_t"] = torch.empty(cl.acts_floats(B), **f)
+        ws["acts_c"] = torch.empty(cl.acts_floats(B), **f)
+        ws["dy"] = torch.zeros((2, B, cl.ld_out), **f)
+        ws["grads"] = torch.zeros(cl.total, **f)
+        ws["splits"] = default_splits(B)
+        ws["bwd"] = torch.empty(cl.bwd_ws_floats(B, ws["splits"]), **f)
+        ws["scratch"] = torch.zeros(2048, **f)
+        self._ws = ws
+        return ws
+
+    def _norm_ptrs(self):
+        if not self.cfg.algo.obs_norm or self.normalize_tuple is None:
+            return None, None, 0.0
+        mean, var, eps = self.normalize_tuple
+        return mean, var, float(eps)
+
+    def _step_kernels(self, ws, idx, draw):
+        """The launch sequence of one critic gradient step; everything asynchronous on the current stream."""
+        algo, dev, B = self.cfg.algo, self.device, ws["B"]
+        O = self.memory.ring.O
+        st = L.stream(dev)
+        mean, var, eps = self._norm_ptrs()
+        L.check(L.lib.pqlk_replay_gather_fused(C.byref(self.memory.ring.desc), L.ptr(idx), B, L.ptr(mean), L.ptr(var), eps, 1,
+                                               L.ptr(ws["x_sa"]), ws["ld_sa"], L.ptr(ws["xn_sa"]), L.ptr(ws["xn_obs"]),
+                                               ws["ld_o"], L.ptr(ws["rew"]), L.ptr(ws["done"]), st))
+        al, cl = self.actor.layout, self.critic.layout
+        # target policy smoothing (:63-71): a' written into the action columns of the target critic's input
+        xn_act = ws["xn_sa"][:, O:]
+        L.check(L.lib.pqlk_mlp_forward(C.byref(al.desc), L.ptr(self.actor.arena.data), L.ptr(ws["xn_obs"]), ws["ld_o"], B,
+                                       L.ACT_TANH_NOISE, L.ptr(draw), float(algo.noise.tgt_pol_std),
+                                       float(algo.noise.tgt_pol_noise_bound), L.ptr(ws["acts_a"]), L.ptr(xn_act),
+                                       ws["ld_sa"], st))
+        L.check(L.lib.pqlk_mlp_forward(C.byref(cl.desc), L.ptr(self.critic_target.arena.data), L.ptr(ws["xn_sa"]),
+                                       ws["ld_sa"], B, L.ACT_NONE, None, 0.0, 0.0, L.ptr(ws["acts_t"]), None, 0, st))
+        L.check(L.lib.pqlk_mlp_forward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
+                                       L.ACT_NONE, None, 0.0, 0.0, L.ptr(ws["acts_c"]), None, 0, st))
+        q = output_view(cl, ws["acts_c"], B)
+        qt = output_view(cl, ws["acts_t"], B)
+        gamma_n = float(algo.gamma) ** int(algo.nstep)
+        if algo.distl:
+            L.check(L.lib.pqlk_c51_bce_loss(L.ptr(q), L.ptr(qt), cl.ld_out, int(algo.num_atoms), L.ptr(ws["rew"]),
+                                            L.ptr(ws["done"]), L.ptr(self.critic.z_atoms), gamma_n, float(algo.v_min),
+                                            float(algo.v_max), B, L.ptr(ws["dy"]), L.ptr(self.loss_ring), L.ptr(self.opt.step),
+                                            LOSS_RING, None, L.ptr(ws["scratch"]), st))
+        else:
+            L.check(L.lib.pqlk_td_mse_loss(L.ptr(q), L.ptr(qt), cl.ld_out, L.ptr(ws["rew"]), L.ptr(ws["done"]), gamma_n, B,
+                                           L.ptr(ws["dy"]), L.ptr(self.loss_ring), L.ptr(self.opt.step), LOSS_RING,
+                                           L.ptr(ws["scratch"]), st))
+        L.check(L.lib.pqlk_mlp_backward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
+                                        L.ptr(ws["acts_c"]), L.ptr(ws["dy"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0, 0,
+                                        None, 0, L.ptr(ws["bwd"]), ws["bwd"].numel(), st))
+        if self.world > 1:  # data-parallel: sum over ranks on RCCL, mean folded into the optimiser's grad_scale
+            torch.distributed.all_reduce(ws["grads"], group=self.pg)
+        apply_optimizer(self.critic.arena.data, ws["grads"], self.opt, self.critic_target.arena.data, algo.critic_lr,
+                        algo.max_grad_norm, algo.tau, 1.0 / self.world, dev)
+
+    def _draw_and_step(self, ws):
+        B = ws["B"]
+        # RNG consumption order of the reference: one randint(cur_capacity,(B,)) then one
+        # N(0,1) draw of shape (B, A) on the learner's device generator.
+        ws["idx"].copy_(torch.randint(self.memory.cur_capacity, size=(B,), device=self.device))
+        ws["draw"].normal_()
+        self._step_kernels(ws, ws["idx"], ws["draw"])
+
+    @torch.no_grad()
+    def learn(self, indices=None, noise=None):
+        """One critic gradient step.  `indices` (B,) int64 and `noise` (B,A) N(0,1) draws may be injected
+        for parity tests; otherwise they are drawn exactly like the reference draws them."""
+        if self.actor is None:
+            return self.sleep_time
+        B = int(self.cfg.algo.batch_size)
+        with torch.cuda.device(self.device):
+            ws = self._workspace(B)
+            if indices is not None or noise is not None:
+                idx = (indices.to(self.device, torch.int64).contiguous() if indices is not None
+                       else torch.randint(self.memory.cur_capacity, size=(B,), device=self.device))
+                draw = (noise.to(self.device, torch.float32).contiguous() if noise is not None
+                        else torch.empty((B, self.action_dim), device=self.device).normal_())
+                self._step_kernels(ws, idx, draw)
+            elif self.use_graph:
+                key = (B, self.memory.cur_capacity, id(self.actor), self.normalize_tuple is None)
+                if self._graph is None or self._graph_key != key:
+                    self._capture(ws, key)
+                self._graph.replay()
+            else:
+                self._draw_and_step(ws)
+        self.update_count += 1
+        return self.sleep_time
+
+    def _capture(self, ws, key):
+        """Capture the whole step (RNG draws included) into a hipGraph.  The graph bakes in
+        cur_capacity (the randint bound), so it is re-captured while the ring is still filling."""
+        # warm-up outside capture (lazy hipFuncSetAttribute / allocator state), on a side stream as torch requires
+        snap = self._snapshot()
+        s = torch.cuda.Stream(self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            self._draw_and_step(ws)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        self._restore(snap)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._draw_and_step(ws)
+        self._restore(snap)  # capture does not execute, but keep state exactly as before
+        self._graph, self._graph_key = g, key
+
+    def _snapshot(self):
+        return [t.clone() for t in (self.critic.arena.data, self.critic_target.arena.data, self.opt.m, self.opt.v,
+                                    self.opt.step, self.loss_ring)], torch.cuda.get_rng_state(self.device)
+
+    def _restore(self, snap):
+        tensors, rng = snap
+        for dst, src in zip((self.critic.arena.data, self.critic_target.arena.data, self.opt.m, self.opt.v, self.opt.step,
+                             self.loss_ring), tensors):
+            dst.copy_(src)
+        torch.cuda.set_rng_state(rng, self.device)
+
+    # ------------------------------------------------------------------------------------------
+    def loss_mean(self):
+        """Mean of the last 5 critic losses (Tracker(5).mean(), zero-filled before 5 steps) -- one host sync."""
+        vals = self.loss_ring.tolist()
+        n = min(self.update_count, LOSS_RING)
+        # ring slot of step t (1-based counter after increment happens later in the step) is (t-1) % 5
+        self.loss_tracker = Tracker(LOSS_RING)
+        for t in range(self.update_count - n, self.update_count):
+            self.loss_tracker.update(vals[t % LOSS_RING])
+        return self.loss_tracker.mean()
+
+    def set_actor(self, actor):
+        """Adopt new policy weights.  A pql_amd actor on another GPU is copied arena-to-arena (peer copy
+        over xGMI) into a resident replica instead of re-materialising a module."""
+        if self.actor is None or self.actor.layout.dims != actor.layout.dims:
+            self.actor = deepcopy(actor).to(self.device)
+        elif actor is not self.actor:
+            self.actor.arena.data.copy_(actor.arena.data, non_blocking=True)
+
+    @torch.no_grad()
+    def update(self, actor, trajectory, normalize_tuple, sleep_time):
+        self.set_actor(actor)
+        self.memory.add_to_buffer(trajectory)
+        self.normalize_tuple = resident_norm(self, normalize_tuple)
+        self.sleep_time = sleep_time
+        return self.critic, self.loss_mean(), self.update_count
+
+
+def asyn_v_learner(learner, cfg, stop_event=None):
+    """Free-running pump (reference: a Ray task looping forever, :136-141).  Run it in a thread."""
+    while stop_event is None or not stop_event.is_set():
+        sleep_time = learner.learn()
+        if sleep_time:
+            time.sleep(sleep_time)

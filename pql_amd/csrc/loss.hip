@@ -8,7 +8,8 @@
 
 // sum `n` partials in fixed order with one block -> out[0] = scale * sum
 __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part, int n, float scale,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, const int32_t* __restrict__ slot_dev,
+                                                      int ring_len) {
   __shared__ float sh[256];
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) s += part[i];
@@ -18,7 +19,7 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ 
     if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = sh[0] * scale;
+  if (threadIdx.x == 0) out[slot_dev ? (slot_dev[0] % ring_len) : 0] = sh[0] * scale;
 }
 
 __device__ __forceinline__ float block_sum_256(float v) {
@@ -57,16 +58,18 @@ __global__ __launch_bounds__(256) void k_td_mse(const float* __restrict__ q, con
 }
 
 extern "C" int pqlk_td_mse_loss(const float* q, const float* qt, int64_t ld, const float* rew, const float* done,
-                                float gamma_n, int64_t b, float* dy, float* loss_out, float* scratch,
-                                pqlk_stream_t stream) {
+                                float gamma_n, int64_t b, float* dy, float* loss_out, const int32_t* slot_dev,
+                                int32_t ring_len, float* scratch, pqlk_stream_t stream) {
   PQLK_REQUIRE(q && qt && rew && done && dy && loss_out && scratch, PQLK_E_NULL);
+  PQLK_REQUIRE(!slot_dev || ring_len > 0, PQLK_E_SHAPE);
   PQLK_REQUIRE(b > 0, PQLK_E_SHAPE);
   PQLK_REQUIRE(ld >= 32 && ld % 32 == 0, PQLK_E_ALIGN);
   int blocks = (int)((b + 255) / 256);
   if (blocks > LOSS_MAX_BLOCKS) blocks = LOSS_MAX_BLOCKS;
   hipLaunchKernelGGL(k_td_mse, dim3(blocks), dim3(256), 0, pqlk_s(stream), q, qt, ld, rew, done, gamma_n, b, dy, scratch);
   PQLK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, pqlk_s(stream), scratch, blocks, 1.0f / (float)b, loss_out);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, pqlk_s(stream), scratch, blocks, 1.0f / (float)b, loss_out,
+                     slot_dev, (int)ring_len);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }
@@ -189,9 +192,10 @@ __global__ __launch_bounds__(256) void k_c51_bce(const float* __restrict__ logit
 
 extern "C" int pqlk_c51_bce_loss(const float* logits, const float* logits_t, int64_t ld, int32_t k, const float* rew,
                                  const float* done, const float* support, float gamma_n, float v_min, float v_max,
-                                 int64_t b, float* dy, float* loss_out, float* proj_out, float* scratch,
-                                 pqlk_stream_t stream) {
+                                 int64_t b, float* dy, float* loss_out, const int32_t* slot_dev, int32_t ring_len,
+                                 float* proj_out, float* scratch, pqlk_stream_t stream) {
   PQLK_REQUIRE(logits && logits_t && rew && done && support && dy && loss_out && scratch, PQLK_E_NULL);
+  PQLK_REQUIRE(!slot_dev || ring_len > 0, PQLK_E_SHAPE);
   PQLK_REQUIRE(b > 0 && k >= 2, PQLK_E_SHAPE);
   PQLK_REQUIRE(k <= 64, PQLK_E_UNSUPPORTED);
   PQLK_REQUIRE(ld % 32 == 0 && ld >= k, PQLK_E_ALIGN);
@@ -202,7 +206,7 @@ extern "C" int pqlk_c51_bce_loss(const float* logits, const float* logits_t, int
                      support, gamma_n, v_min, v_max, dz, b, dy, proj_out, scratch);
   PQLK_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, pqlk_s(stream), scratch, blocks,
-                     1.0f / ((float)b * (float)k), loss_out);
+                     1.0f / ((float)b * (float)k), loss_out, slot_dev, (int)ring_len);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }
@@ -265,8 +269,10 @@ __global__ __launch_bounds__(256) void k_dpg_dist(const float* __restrict__ logi
 }
 
 extern "C" int pqlk_dpg_loss(const float* q, int64_t ld, int32_t k, const float* support, int64_t b, float* dy,
-                             float* loss_out, float* scratch, pqlk_stream_t stream) {
+                             float* loss_out, const int32_t* slot_dev, int32_t ring_len, float* scratch,
+                             pqlk_stream_t stream) {
   PQLK_REQUIRE(q && dy && loss_out && scratch, PQLK_E_NULL);
+  PQLK_REQUIRE(!slot_dev || ring_len > 0, PQLK_E_SHAPE);
   PQLK_REQUIRE(b > 0 && k >= 1, PQLK_E_SHAPE);
   PQLK_REQUIRE(k <= 64, PQLK_E_UNSUPPORTED);
   PQLK_REQUIRE(ld % 32 == 0 && ld >= k, PQLK_E_ALIGN);
@@ -282,7 +288,8 @@ extern "C" int pqlk_dpg_loss(const float* q, int64_t ld, int32_t k, const float*
     hipLaunchKernelGGL(k_dpg_dist, dim3(blocks), dim3(256), 0, pqlk_s(stream), q, ld, (int)k, support, b, dy, scratch);
   }
   PQLK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, pqlk_s(stream), scratch, blocks, -1.0f / (float)b, loss_out);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, pqlk_s(stream), scratch, blocks, -1.0f / (float)b, loss_out,
+                     slot_dev, (int)ring_len);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }

@@ -34,7 +34,7 @@ struct AdamC {
   float w1;           // 1 - b1      (lerp weight)
   float b2, one_m_b2;
   float eps, tau, one_m_tau;
-  float max_norm;
+  float max_norm, grad_scale;
   double lr, b1d, b2d;
 };
 
@@ -54,10 +54,10 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const float total = sqrtf(sh[0]);
+    const float total = sqrtf(sh[0]) * c.grad_scale;  // norm of the scaled gradient
     float coef = 1.f;
     if (c.max_norm > 0.f) coef = fminf(c.max_norm / (total + 1e-6f), 1.f);  // clip_grad_norm_
-    s_coef = coef;
+    s_coef = coef * c.grad_scale;
     const int t = step_dev[0];
     const double bc1 = 1.0 - pow(c.b1d, (double)t);
     const double bc2 = 1.0 - pow(c.b2d, (double)t);
@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
   }
 }
 
-extern "C" int pqlk_clip_adamw_polyak(float* p, float* g, float* m, float* v, float* target, int64_t n, float max_norm,
+extern "C" int pqlk_clip_adamw_polyak(float* p, float* g, float* m, float* v, float* target, int64_t n, float grad_scale,
+                                      float max_norm,
                                       float lr, float b1, float b2, float eps, float wd, float tau, int32_t* step_dev,
                                       float* gnorm_out, float* scratch, pqlk_stream_t stream) {
   PQLK_REQUIRE(p && g && m && v && step_dev && scratch, PQLK_E_NULL);
@@ -103,6 +104,7 @@ extern "C" int pqlk_clip_adamw_polyak(float* p, float* g, float* m, float* v, fl
   c.tau = tau;
   c.one_m_tau = (float)(1.0 - (double)tau);
   c.max_norm = max_norm;
+  c.grad_scale = grad_scale;
   c.lr = (double)lr;
   c.b1d = (double)b1;
   c.b2d = (double)b2;

@@ -85,8 +85,9 @@ def test_gather_fused_bit_exact(dev, ref, O, A):
     f = dict(dtype=torch.float32, device=dev)
     x_sa = torch.full((B, ld_sa), 9.0, **f); xn_sa = torch.full((B, ld_sa), 9.0, **f); xn_o = torch.full((B, ld_o), 9.0, **f)
     rew = torch.empty(B, **f); done = torch.empty(B, **f)
-    L.check(L.lib.pqlk_replay_gather_fused(C.byref(rb.ring.desc), L.ptr(idx.to(dev)), B, L.ptr(mean.to(dev)),
-                                           L.ptr(var.to(dev)), 1e-4, 1, L.ptr(x_sa), ld_sa, L.ptr(xn_sa), L.ptr(xn_o), ld_o,
+    idx_d, mean_d, var_d = idx.to(dev), mean.to(dev), var.to(dev)   # keep device inputs alive across the async launch
+    L.check(L.lib.pqlk_replay_gather_fused(C.byref(rb.ring.desc), L.ptr(idx_d), B, L.ptr(mean_d),
+                                           L.ptr(var_d), 1e-4, 1, L.ptr(x_sa), ld_sa, L.ptr(xn_sa), L.ptr(xn_o), ld_o,
                                            L.ptr(rew), L.ptr(done), L.stream(dev)))
     x_sa, xn_sa, xn_o = x_sa.cpu(), xn_sa.cpu(), xn_o.cpu()
     assert torch.equal(x_sa[:, :O], on) and torch.equal(x_sa[:, O:O + A], a)
@@ -112,7 +113,8 @@ def test_obs_ring_gather(dev, ref):
     assert torch.equal(ring.records[:, :O].cpu(), oracle.mem)
     idx = T(dd.integers((B,), 9, cur))
     x_sa = torch.full((B, L.ld(O + 3)), 7.0, device=dev); x_o = torch.full((B, L.ld(O)), 7.0, device=dev)
-    L.check(L.lib.pqlk_replay_gather_fused(C.byref(ring.desc), L.ptr(idx.to(dev)), B, None, None, 0.0, 1, L.ptr(x_sa),
+    idx_d = idx.to(dev)
+    L.check(L.lib.pqlk_replay_gather_fused(C.byref(ring.desc), L.ptr(idx_d), B, None, None, 0.0, 1, L.ptr(x_sa),
                                            x_sa.stride(0), None, L.ptr(x_o), x_o.stride(0), None, None, L.stream(dev)))
     assert torch.equal(x_o[:, :O].cpu(), oracle.gather(idx)) and torch.all(x_o[:, O:] == 0)
     assert torch.equal(x_sa[:, :O].cpu(), oracle.gather(idx)) and torch.all(x_sa[:, O:] == 0)
@@ -315,8 +317,9 @@ def test_td_mse_loss(dev, ref, B):
     loss.backward()
     ld = 32
     dy = torch.full((2, B, ld), 5.0, device=dev); lo = torch.zeros(1, device=dev); scr = torch.zeros(2048, device=dev)
-    L.check(L.lib.pqlk_td_mse_loss(L.ptr(_pad(q, ld).to(dev)), L.ptr(_pad(qt, ld).to(dev)), ld, L.ptr(rew.to(dev)),
-                                   L.ptr(done.to(dev)), gn, B, L.ptr(dy), L.ptr(lo), L.ptr(scr), L.stream(dev)))
+    qd, qtd, rd, dd_ = _pad(q, ld).to(dev), _pad(qt, ld).to(dev), rew.to(dev), done.to(dev)
+    L.check(L.lib.pqlk_td_mse_loss(L.ptr(qd), L.ptr(qtd), ld, L.ptr(rd),
+                                   L.ptr(dd_), gn, B, L.ptr(dy), L.ptr(lo), None, 0, L.ptr(scr), L.stream(dev)))
     np.testing.assert_allclose(lo.item(), loss.item(), rtol=2e-6)
     np.testing.assert_allclose(dy[:, :, :1].cpu().numpy(), qr.grad.numpy(), rtol=1e-6, atol=1e-10)
     assert torch.all(dy[:, :, 1:] == 0)
@@ -338,8 +341,9 @@ def test_c51_bce_loss(dev, ref, B):
     loss.backward()
     dy = torch.full((2, B, ld), 5.0, device=dev); lo = torch.zeros(1, device=dev); scr = torch.zeros(2048, device=dev)
     pj = torch.empty((B, K), device=dev)
-    L.check(L.lib.pqlk_c51_bce_loss(L.ptr(_pad(lg, ld).to(dev)), L.ptr(_pad(lt, ld).to(dev)), ld, K, L.ptr(rew.view(-1).to(dev)),
-                                    L.ptr(done.view(-1).to(dev)), L.ptr(z.to(dev)), gn, -10.0, 10.0, B, L.ptr(dy), L.ptr(lo),
+    lgd, ltd, rd, dd_, zd = _pad(lg, ld).to(dev), _pad(lt, ld).to(dev), rew.view(-1).to(dev), done.view(-1).to(dev), z.to(dev)
+    L.check(L.lib.pqlk_c51_bce_loss(L.ptr(lgd), L.ptr(ltd), ld, K, L.ptr(rd),
+                                    L.ptr(dd_), L.ptr(zd), gn, -10.0, 10.0, B, L.ptr(dy), L.ptr(lo), None, 0,
                                     L.ptr(pj), L.ptr(scr), L.stream(dev)))
     np.testing.assert_allclose(pj.cpu().numpy(), tgt.numpy(), atol=2e-7)
     np.testing.assert_allclose(lo.item(), loss.item(), rtol=5e-6)
@@ -362,7 +366,8 @@ def test_dpg_loss(dev, K):
         loss = -torch.min(e[0], e[1]).mean()
     loss.backward()
     dy = torch.full((2, B, ld), 5.0, device=dev); lo = torch.zeros(1, device=dev); scr = torch.zeros(2048, device=dev)
-    L.check(L.lib.pqlk_dpg_loss(L.ptr(_pad(q, ld).to(dev)), ld, K, L.ptr(z.to(dev)) if K > 1 else None, B, L.ptr(dy), L.ptr(lo),
+    qd = _pad(q, ld).to(dev); zd = z.to(dev) if K > 1 else None
+    L.check(L.lib.pqlk_dpg_loss(L.ptr(qd), ld, K, L.ptr(zd), B, L.ptr(dy), L.ptr(lo), None, 0,
                                 L.ptr(scr), L.stream(dev)))
     np.testing.assert_allclose(lo.item(), loss.item(), rtol=5e-6)
     np.testing.assert_allclose(dy[:, :, :K].cpu().numpy(), qr.grad.numpy(), rtol=5e-5, atol=1e-9)
@@ -384,7 +389,7 @@ def test_clip_adamw_polyak_trace(dev, ref):
         opt.apply([g.clone()], 0.5)
         ref.polyak_ref(tgt, opt.params, 0.05)
         gd = g.to(dev)
-        L.check(L.lib.pqlk_clip_adamw_polyak(L.ptr(p), L.ptr(gd), L.ptr(m), L.ptr(v), L.ptr(tg), n, 0.5, 5e-4, 0.9, 0.999,
+        L.check(L.lib.pqlk_clip_adamw_polyak(L.ptr(p), L.ptr(gd), L.ptr(m), L.ptr(v), L.ptr(tg), n, 1.0, 0.5, 5e-4, 0.9, 0.999,
                                              1e-8, 1e-2, 0.05, L.ptr(step), L.ptr(gn), L.ptr(scr), L.stream(dev)))
         np.testing.assert_allclose(gn.item(), norm_ref, rtol=1e-5)
         np.testing.assert_allclose(p.cpu().numpy(), opt.params[0].numpy(), rtol=2e-6, atol=1e-8)

@@ -1,0 +1,169 @@
+"""Learner-level parity on the GPU: PQLVLearner.learn / PQLPLearner.learn (HIP launch sequences) against
+(a) the golden step traces the reference produced (tests/golden/learners.npz: identical replay samples and
+noise injected) and (b) the CPU oracle at the BASELINE batch size.  Run with `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+import detdata as dd
+
+pytestmark = pytest.mark.gpu
+
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def make_cfg(distl=False, B=64, memory=400, hidden=None, graph=False, nstep=3):
+    from pql_amd.utils.cfg import load_cfg
+    ov = [f"algo.batch_size={B}", f"algo.memory_size={memory}", f"algo.distl={distl}", "algo.v_learner_gpu=0",
+          "algo.p_learner_gpu=0", "algo.num_gpus=1", f"algo.graph={graph}", f"algo.nstep={nstep}"]
+    cfg = load_cfg(ov)
+    cfg.algo.hidden_layers = hidden
+    return cfg
+
+
+def _sd(state):
+    return {k: T(v) for k, v in state.items()}
+
+
+def _fill(O, A, rows, seed):
+    return (T(dd.uniform((rows, O), seed, -3, 3)), T(dd.uniform((rows, A), seed + 1)), T(dd.uniform((rows, 1), seed + 2, -0.05, 0.05)),
+            T(dd.uniform((rows, O), seed + 3, -3, 3)), T(dd.bernoulli((rows, 1), seed + 4, 0.1)))
+
+
+def _check_module(module, g, prefix, rtol=5e-5, atol=5e-7):
+    for key, view in module.named_views():
+        np.testing.assert_allclose(dd.summarize(view.cpu().numpy()), g[f"{prefix}{key}"], rtol=rtol, atol=atol,
+                                   err_msg=prefix + key)
+
+
+@pytest.mark.parametrize("distl", [False, True])
+def test_v_learner_golden_trace(golden, dev, distl):
+    from pql_amd.algo.pql_v_learner import PQLVLearner
+    from pql_amd.models.mlp import TanhMLPPolicy
+    g = golden("learners"); tag = "vd" if distl else "v"; O, A = 8, 2
+    v = PQLVLearner((O,), A, make_cfg(distl))
+    v.critic.load_state_dict(_sd(dd.doubleq_state(O, A, 51 if distl else 1, 31 if distl else 21)))
+    v.critic_target.arena.data.copy_(v.critic.arena.data)
+    actor = TanhMLPPolicy((O,), A).to(dev); actor.load_state_dict(_sd(dd.mlp_state(O, A, 11)))
+    norm = (T(g["learner_norm_mean"]).to(dev), T(g["learner_norm_var"]).to(dev), 1e-4)
+    critic, loss_mean, count = v.update(actor, tuple(t.to(dev) for t in _fill(O, A, 300, 810)), norm, 0)
+    assert critic is v.critic and count == 0 and loss_mean == 0
+    for s in range(3):
+        v.learn(indices=T(g[f"{tag}_idx"][s]), noise=T(g[f"{tag}_noise"][s]))
+        loss = v.loss_ring[s % 5].item()
+        np.testing.assert_allclose(loss, g[f"{tag}_loss"][s], rtol=2e-5)
+        _check_module(v.critic, g, f"{tag}_s{s}_p_")
+        _check_module(v.critic_target, g, f"{tag}_s{s}_t_")
+    assert v.update_count == 3 and v.opt.step.item() == int(g[f"{tag}_adam_step"])
+    np.testing.assert_allclose(v.critic.state_dict()["net_q1.net.6.weight"].cpu().numpy(), g[f"{tag}_final_q1_last_w"],
+                               rtol=5e-5, atol=5e-7)
+    lay = v.critic.layout
+    np.testing.assert_allclose(dd.summarize(lay.weight(v.opt.m, 0, 0).cpu().numpy()), g[f"{tag}_adam_m0"], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(dd.summarize(lay.weight(v.opt.v, 0, 0).cpu().numpy()), g[f"{tag}_adam_v0"], rtol=1e-4, atol=1e-12)
+    np.testing.assert_allclose(v.loss_mean(), np.mean([0, 0, *g[f"{tag}_loss"]]), rtol=2e-5)   # Tracker(5) semantics
+
+
+@pytest.mark.parametrize("distl", [False, True])
+def test_p_learner_golden_trace(golden, dev, distl):
+    from pql_amd.algo.pql_p_learner import PQLPLearner
+    from pql_amd.models.mlp import DistributionalDoubleQ, DoubleQ
+    g = golden("learners"); tag = "pd" if distl else "p"; O, A = 8, 2
+    p = PQLPLearner((O,), A, make_cfg(distl))
+    p.actor.load_state_dict(_sd(dd.mlp_state(O, A, 11)))
+    if distl:
+        critic = DistributionalDoubleQ((O,), A, v_min=-10, v_max=10, num_atoms=51, device=dev).to(dev)
+        critic.load_state_dict(_sd(dd.doubleq_state(O, A, 51, 31)))
+    else:
+        critic = DoubleQ((O,), A).to(dev); critic.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 21)))
+    norm = (T(g["learner_norm_mean"]).to(dev), T(g["learner_norm_var"]).to(dev), 1e-4)
+    actor, _, count = p.update(critic, _fill(O, A, 300, 810)[0].to(dev), norm, 0)
+    assert actor is p.actor and count == 0 and (p.next_p, p.cur_capacity) == (300, 300)
+    for s in range(3):
+        p.learn(indices=T(g[f"{tag}_idx"][s]))
+        np.testing.assert_allclose(p.loss_ring[s % 5].item(), g[f"{tag}_loss"][s], rtol=2e-5)
+        if not distl:
+            _check_module(p.actor, g, f"p_s{s}_p_")
+    np.testing.assert_allclose(p.actor.state_dict()["net.6.weight"].cpu().numpy(), g[f"{tag}_final_last_w"], rtol=5e-5, atol=5e-7)
+
+
+def test_learn_is_noop_before_first_update(dev):
+    from pql_amd.algo.pql_p_learner import PQLPLearner
+    from pql_amd.algo.pql_v_learner import PQLVLearner
+    v = PQLVLearner((8,), 2, make_cfg()); p = PQLPLearner((8,), 2, make_cfg())
+    assert v.learn() == 0 and v.update_count == 0        # pql_v_learner.py:74
+    assert p.learn() == 0.01 and p.update_count == 0     # pql_p_learner.py:48, sleep_time default 0.01
+
+
+@pytest.mark.parametrize("hidden", [None, [512, 512, 256]])
+def test_full_size_step_vs_oracle(dev, hidden):
+    """cfg #2 shapes (obs 88, act 16, batch 8192), reference-default and BASELINE hidden sizes: two V steps and
+    two P steps with injected samples vs the CPU oracle; Q-side loss at 1e-5 relative, parameters at 1e-5."""
+    from oracle import pql_ref_cpu as ref
+    from pql_amd.algo.pql_p_learner import PQLPLearner
+    from pql_amd.algo.pql_v_learner import PQLVLearner
+    O, A, B, cap = 88, 16, 8192, 20000
+    hid = tuple(hidden) if hidden else (512, 256, 128)
+    cfg = make_cfg(False, B=B, memory=cap, hidden=hidden)
+    v = PQLVLearner((O,), A, cfg); p = PQLPLearner((O,), A, cfg)
+    cst = dd.doubleq_state(O, A, 1, 21, hid); ast = dd.mlp_state(O, A, 11, hid)
+    v.critic.load_state_dict(_sd(cst)); v.critic_target.arena.data.copy_(v.critic.arena.data)
+    p.actor.load_state_dict(_sd(ast))
+    data = _fill(O, A, cap - 100, 77)
+    mean, var = T(dd.uniform((O,), 801, -0.5, 0.5)), T(dd.uniform((O,), 802, 0.5, 2.0))
+    hp = ref.HyperRef(batch_size=B)
+    vr = ref.VLearnerRef(O, A, hp, cap, ref.params_from_state(cst, "net_q1.net."), ref.params_from_state(cst, "net_q2.net."))
+    pr = ref.PLearnerRef(O, A, hp, cap, ref.params_from_state(ast))
+    vr.update(ref.params_from_state(ast), data, (mean, var, 1e-4))
+    pr.update(vr.q1, vr.q2, data[0], (mean, var, 1e-4))
+    norm = (mean.to(dev), var.to(dev), 1e-4)
+    v.update(p.actor, tuple(t.to(dev) for t in data), norm, 0)
+    p.update(v.critic, data[0].to(dev), norm, 0)
+    for s in range(2):
+        idx = T(dd.integers((B,), 900 + s, cap - 100)); draw = T(dd.uniform((B, A), 950 + s, -2, 2))
+        lv = vr.learn(idx=idx, draw=draw)
+        v.learn(indices=idx, noise=draw)
+        np.testing.assert_allclose(v.loss_ring[s % 5].item(), lv, rtol=1e-5)
+        lp = pr.learn(idx=idx)
+        p.learn(indices=idx)
+        np.testing.assert_allclose(p.loss_ring[s % 5].item(), lp, rtol=1e-5, atol=1e-7)
+    lay = v.critic.layout
+    k = 0
+    for n, net in enumerate((vr.q1, vr.q2)):
+        for l in range(lay.n_layers):
+            np.testing.assert_allclose(lay.weight(v.critic.arena.data, n, l).cpu().numpy(), net[2 * l].detach().numpy(),
+                                       rtol=1e-5, atol=2e-6)
+            np.testing.assert_allclose(lay.bias(v.critic.arena.data, n, l).cpu().numpy(), net[2 * l + 1].detach().numpy(),
+                                       rtol=1e-5, atol=2e-6)
+    al = p.actor.layout
+    for l in range(al.n_layers):
+        np.testing.assert_allclose(al.weight(p.actor.arena.data, 0, l).cpu().numpy(), pr.actor[2 * l].detach().numpy(),
+                                   rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(lay.weight(v.critic_target.arena.data, 0, 0).cpu().numpy(), vr.t1[0].numpy(), rtol=1e-5, atol=2e-6)
+
+
+def test_graph_replay_matches_eager(dev):
+    """hipGraph-captured learn() is the same launch sequence: with equal seeds it must reproduce the eager
+    parameters bit for bit (same kernels, same order, same RNG offsets)."""
+    from pql_amd.algo.pql_v_learner import PQLVLearner
+    from pql_amd.models.mlp import TanhMLPPolicy
+    O, A, B, cap = 8, 2, 256, 2000
+    actor = TanhMLPPolicy((O,), A).to(dev); actor.load_state_dict(_sd(dd.mlp_state(O, A, 11)))
+    outs = []
+    for graph in (False, True):
+        v = PQLVLearner((O,), A, make_cfg(False, B=B, memory=cap, graph=graph))
+        v.critic.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 21))); v.critic_target.arena.data.copy_(v.critic.arena.data)
+        v.update(actor, tuple(t.to(dev) for t in _fill(O, A, cap, 5)), None, 0)
+        torch.manual_seed(1234)
+        for _ in range(4):
+            v.learn()
+        torch.cuda.synchronize()
+        outs.append((v.critic.arena.data.clone(), v.critic_target.arena.data.clone(), v.loss_ring.clone(), v.opt.step.item()))
+    assert outs[0][3] == outs[1][3] == 4
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
