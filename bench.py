@@ -206,8 +206,9 @@ def cpu_baseline(args, O, A, hidden):
     cores, same schedule, bounded sample."""
     import numpy as np
     from oracle import pql_ref_cpu as ref
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
+    # the GPU box gives one-GPU jobs a 16-core share; more threads than cores makes MKL crawl
+    cores = int(os.environ.get("PQL_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+    torch.set_num_threads(cores)
     B, N, cap = args.batch, args.num_envs, min(args.replay, 200_000)   # smaller resident ring: CPU RAM/time bound
     g = torch.Generator().manual_seed(0)
     dims_a = ref.layer_dims(O, A, hidden)
@@ -278,8 +279,15 @@ def main():
         pg = torch.distributed.group.WORLD
     torch.manual_seed(42 + rank)
 
+    def note(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
     cfg, env, actor, v, p = build_system(args, rank, world, device, pg)
+    note("system built")
     prefill(actor, v, p, env, cfg, args, device)
+    note(f"replay pre-filled: {v.memory.cur_capacity} rows x {v.memory.ring.rec_ld * 4} B")
     sched = Schedule(actor, v, p, env, cfg, device, v_only=args.v_only)
 
     def barrier():
@@ -288,6 +296,8 @@ def main():
 
     for _ in range(args.warmup):
         sched.step()
+    torch.cuda.synchronize(device)
+    note("warm-up done")
     barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -296,6 +306,7 @@ def main():
     torch.cuda.synchronize(device)
     barrier()
     dt = time.perf_counter() - t0
+    note(f"timed {args.steps} steps in {dt:.3f} s")
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX, group=pg)
@@ -334,8 +345,10 @@ def main():
         line["roofline_gather"] = {"bound": "hbm", "kernel": "k_replay_gather_fused", "achieved": alg_bytes / (gms * 1e-3) / 1e9,
                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_bytes / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                    "traffic": None, "us_per_launch": gms * 1e3, "record_bytes": rec_ld * 4}
+        note("roofline sections measured")
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, O, A, hidden)
+            note("cpu baseline done")
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if world > 1:

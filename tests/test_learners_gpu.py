@@ -103,7 +103,9 @@ def test_learn_is_noop_before_first_update(dev):
 @pytest.mark.parametrize("hidden", [None, [512, 512, 256]])
 def test_full_size_step_vs_oracle(dev, hidden):
     """cfg #2 shapes (obs 88, act 16, batch 8192), reference-default and BASELINE hidden sizes: two V steps and
-    two P steps with injected samples vs the CPU oracle; Q-side loss at 1e-5 relative, parameters at 1e-5."""
+    two P steps with injected samples vs the CPU oracle; losses at 1e-5 relative.  Parameters: rtol 1e-5 with
+    atol 1e-5 = 2 % of one Adam step (lr 5e-4): Adam divides by sqrt(v), so an entry whose gradient is ~0 turns a
+    1e-9 gradient difference (fp32 summation order over 8192 rows) into a visible fraction of lr."""
     from oracle import pql_ref_cpu as ref
     from pql_amd.algo.pql_p_learner import PQLPLearner
     from pql_amd.algo.pql_v_learner import PQLVLearner
@@ -137,14 +139,14 @@ def test_full_size_step_vs_oracle(dev, hidden):
     for n, net in enumerate((vr.q1, vr.q2)):
         for l in range(lay.n_layers):
             np.testing.assert_allclose(lay.weight(v.critic.arena.data, n, l).cpu().numpy(), net[2 * l].detach().numpy(),
-                                       rtol=1e-5, atol=2e-6)
+                                       rtol=1e-5, atol=1e-5)
             np.testing.assert_allclose(lay.bias(v.critic.arena.data, n, l).cpu().numpy(), net[2 * l + 1].detach().numpy(),
-                                       rtol=1e-5, atol=2e-6)
+                                       rtol=1e-5, atol=1e-5)
     al = p.actor.layout
     for l in range(al.n_layers):
         np.testing.assert_allclose(al.weight(p.actor.arena.data, 0, l).cpu().numpy(), pr.actor[2 * l].detach().numpy(),
-                                   rtol=1e-5, atol=2e-6)
-    np.testing.assert_allclose(lay.weight(v.critic_target.arena.data, 0, 0).cpu().numpy(), vr.t1[0].numpy(), rtol=1e-5, atol=2e-6)
+                                   rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lay.weight(v.critic_target.arena.data, 0, 0).cpu().numpy(), vr.t1[0].numpy(), rtol=1e-5, atol=1e-5)
 
 
 def test_graph_replay_matches_eager(dev):
