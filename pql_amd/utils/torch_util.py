@@ -43,19 +43,23 @@ class RunningMeanStd:
 
     def update(self, x):
         bm, bv = self.batch_moments(x)
+        self.merge_batch(bm, bv, x.shape[0])
+
+    def merge_batch(self, bm, bv, n):
+        """Fold one batch's moments in.  Data parallel (self.pg set): every rank folds in EVERY rank's batch
+        moments, in rank order, so all replicas hold identical statistics; one all-gather of
+        2*obs_dim floats per env step.  Device-agnostic (plain torch + torch.distributed)."""
         pg = getattr(self, "pg", None)
         if pg is None:
-            self.update_from_moments(bm, bv, x.shape[0])
+            self.update_from_moments(bm, bv, n)
             return
-        # data parallel: every rank merges every rank's batch moments in rank order -> identical statistics
-        # everywhere, one small all-gather of 2*obs_dim floats per env step
         world = torch.distributed.get_world_size(pg)
         packed = torch.cat([bm.reshape(-1), bv.reshape(-1)])
         gathered = torch.empty(world * packed.numel(), dtype=packed.dtype, device=packed.device)
         torch.distributed.all_gather_into_tensor(gathered, packed, group=pg)
         gathered = gathered.view(world, 2, -1)
         for r in range(world):
-            self.update_from_moments(gathered[r, 0].view(self.mean.shape), gathered[r, 1].view(self.mean.shape), x.shape[0])
+            self.update_from_moments(gathered[r, 0].view(self.mean.shape), gathered[r, 1].view(self.mean.shape), n)
 
     def update_from_moments(self, batch_mean, batch_var, batch_count):
         delta = batch_mean - self.mean

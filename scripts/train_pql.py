@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Parallel Q-Learning entry point -- same command line as the reference's scripts/train_pql.py
+(`python scripts/train_pql.py task=AllegroHand algo.distl=True algo.num_gpus=1 ...`), same cfg keys, same
+metric names; the Isaac-Gym rollout is replaced by the synthetic vectorised env (task.name picks the shapes).
+
+Orchestration differs by design (SURVEY 3.1 -> MI355X): instead of three Ray processes exchanging pickled
+nn.Modules through the object store, ONE process per GPU issues the sim / V-learner / P-learner launch
+sequences itself, at exactly the ratios the reference's sleep-based controller (train_pql.py:127-158) tries
+to converge to: `critic_sample_ratio` V-steps and `critic_sample_ratio / critic_actor_ratio` P-steps per env
+iteration.  Weights move between the components as flat arena copies (peer-to-peer over xGMI when the
+learners sit on another GPU); transitions go straight from the n-step kernel's output into the replay rings.
+With torchrun (WORLD_SIZE > 1) the env axis and the replay shard data-parallel and gradients are
+all-reduced over RCCL.
+"""
+import os
+import sys
+import time
+from copy import deepcopy
+from itertools import count
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import torch  # noqa: E402
+
+import pql_amd  # noqa: E402,F401
+from pql_amd.algo.pql_actor import PQLActor  # noqa: E402
+from pql_amd.algo.pql_p_learner import PQLPLearner  # noqa: E402
+from pql_amd.algo.pql_v_learner import PQLVLearner  # noqa: E402
+from pql_amd.envs.synthetic import create_task_env  # noqa: E402
+from pql_amd.utils.cfg import load_cfg  # noqa: E402
+from pql_amd.utils.common import capture_keyboard_interrupt, preprocess_cfg, set_random_seed  # noqa: E402
+from pql_amd.utils.logger import MetricLogger  # noqa: E402
+
+
+def should_stop(cfg, start_time, step):
+    """Evaluator.check_if_should_stop (pql/utils/evaluator.py:34-38)."""
+    if cfg.max_step is not None:
+        return step > cfg.max_step
+    return (time.time() - start_time) > cfg.max_time
+
+
+def main(cfg):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    pg = None
+    if world > 1:
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        pg = torch.distributed.group.WORLD
+        cfg.device = cfg.sim_device = cfg.rl_device = f"cuda:{local}"
+        cfg.algo.v_learner_gpu = cfg.algo.p_learner_gpu = local
+        cfg.algo.num_gpus = 1
+    if cfg.algo.num_gpus == 1 and world == 1:
+        cfg.algo.v_learner_gpu = 0
+        cfg.algo.p_learner_gpu = 0
+    if cfg.sim_device == "cuda":
+        cfg.sim_device = cfg.device = cfg.rl_device = "cuda:0"
+    preprocess_cfg(cfg)
+    capture_keyboard_interrupt()
+    set_random_seed(cfg.seed + rank)
+    env = create_task_env(cfg, env_offset=rank * cfg.num_envs)
+    sim_device = torch.device(cfg.sim_device)
+    v_dev = torch.device(f"cuda:{cfg.algo.v_learner_gpu}")
+    p_dev = torch.device(f"cuda:{cfg.algo.p_learner_gpu}")
+
+    pql_actor = PQLActor(env, cfg, env_offset=rank * cfg.num_envs, total_envs=world * cfg.num_envs)
+    v_learner = PQLVLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=pg)
+    p_learner = PQLPLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=pg)
+    if world > 1:
+        for t in (v_learner.critic.arena.data, p_learner.actor.arena.data):
+            torch.distributed.broadcast(t, src=0, group=pg)
+        v_learner.critic_target.arena.data.copy_(v_learner.critic.arena.data)
+        if pql_actor.obs_rms is not None:
+            pql_actor.obs_rms.pg = pg
+    critic, critic_update_times, critic_loss = v_learner.start()
+    actor, actor_update_times, actor_loss = p_learner.start()
+    pql_actor.actor = deepcopy(actor).to(sim_device)
+
+    logger = MetricLogger(cfg.logging.get("jsonl") if cfg.get("logging") else None) if rank == 0 else None
+    start_time = time.time()
+    global_steps = 0
+    pql_actor.reset_agent()
+    p_data, v_data, steps = pql_actor.explore_env(env, cfg.algo.warm_up, random=True)
+    global_steps += steps * world
+    rms = (lambda dev: pql_actor.obs_rms.get_states(dev)) if pql_actor.obs_rms is not None else (lambda dev: None)
+    v_learner.update(actor, v_data, rms(v_dev), 0)
+    p_learner.update(critic, p_data, rms(p_dev), 0)
+
+    v_per_iter = int(cfg.algo.critic_sample_ratio)
+    p_every = int(cfg.algo.critic_actor_ratio)
+    for iter_t in count():
+        p_data, v_data, steps = pql_actor.explore_env(env, cfg.algo.horizon_len, random=False)
+        global_steps += steps * world
+        _, critic_loss, critic_update_times = v_learner.update(pql_actor.actor, v_data, rms(v_dev), 0)
+        _, actor_loss, actor_update_times = p_learner.update(v_learner.critic, p_data, rms(p_dev), 0)
+        pql_actor.actor.arena.data.copy_(p_learner.actor.arena.data, non_blocking=True)
+        for k in range(v_per_iter):
+            v_learner.learn()
+            if k % p_every == p_every - 1:
+                p_learner.learn()
+        if rank == 0 and iter_t % cfg.algo.log_freq == 0:
+            log_info = {
+                "train/critic_loss": critic_loss, "train/actor_loss": actor_loss,
+                "train/return": pql_actor.return_tracker.mean(), "train/episode_length": pql_actor.step_tracker.mean(),
+                "train/critic_update_times": critic_update_times, "train/actor_update_times": actor_update_times,
+                "train/global_steps": global_steps}
+            logger.log(log_info, global_steps)
+            if iter_t % cfg.algo.eval_freq == 0:
+                logger.table(global_steps, log_info)
+        if should_stop(cfg, start_time, global_steps):
+            break
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return dict(global_steps=global_steps, critic_updates=v_learner.update_count, actor_updates=p_learner.update_count)
+
+
+if __name__ == "__main__":
+    print(main(load_cfg(sys.argv[1:])))

@@ -1,0 +1,138 @@
+"""Data-parallel path on CPU with the gloo backend, world_size 2 (the N > 1 layout of bench.py /
+scripts/train_pql.py: env axis + replay shard per rank, ONE gradient all-reduce per step, replicated optimiser).
+
+What runs here is the host-side and collective logic, on CPU tensors:
+  * shard gradients all-reduced and scaled 1/world == the full-batch gradient (SURVEY 8e parity rule),
+    followed by the replicated optimiser step keeping replicas identical;
+  * RunningMeanStd.merge_batch across ranks == single-process merge in rank order;
+  * the synthetic env and the mixed exploration noise index the GLOBAL env axis, so shards reproduce slices.
+The HIP kernels themselves are covered by the -m gpu tests; nothing here launches one."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import detdata as dd
+
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))  # noqa: E731
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, fn, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def run2(fn):
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, fn, ret), nprocs=world, join=True)
+    return [ret[r] for r in range(world)]
+
+
+# --------------------------------------------------------------------------- gradient all-reduce == full batch
+def _dp_grad(rank, world):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import pql_ref_cpu as ref
+    O, A, B = 8, 2, 64
+    st = dd.doubleq_state(O, A, 1, 21)
+    q1 = [p.requires_grad_(True) for p in ref.params_from_state(st, "net_q1.net.")]
+    q2 = [p.requires_grad_(True) for p in ref.params_from_state(st, "net_q2.net.")]
+    obs, act, tgt = T(dd.uniform((B, O), 1, -2, 2)), T(dd.uniform((B, A), 2)), T(dd.uniform((B, 1), 3))
+    sl = slice(rank * B // world, (rank + 1) * B // world)          # rank r takes idx[r*B/G:(r+1)*B/G]
+    a, b = ref.twin_forward_ref(q1, q2, obs[sl], act[sl])
+    loss = torch.nn.functional.mse_loss(a, tgt[sl]) + torch.nn.functional.mse_loss(b, tgt[sl])
+    grads = torch.autograd.grad(loss, [*q1, *q2])
+    flat = torch.cat([g.reshape(-1) for g in grads])                # the flat gradient arena
+    dist.all_reduce(flat)                                           # the ONE collective of a DP step (sum)
+    flat *= 1.0 / world                                             # folded into pqlk_clip_adamw_polyak(grad_scale)
+    opt = ref.AdamWRef([p.detach().clone() for p in (*q1, *q2)])
+    off, gl = 0, []
+    for p in opt.params:
+        gl.append(flat[off: off + p.numel()].view_as(p)); off += p.numel()
+    opt.apply(gl, 0.5)
+    return flat.numpy(), torch.cat([p.reshape(-1) for p in opt.params]).numpy()
+
+
+def test_allreduced_shard_gradients_equal_full_batch_gradient():
+    from oracle import pql_ref_cpu as ref
+    (g0, p0), (g1, p1) = run2(_dp_grad)
+    assert np.array_equal(g0, g1) and np.array_equal(p0, p1)        # replicas stay bit-identical
+    O, A, B = 8, 2, 64
+    st = dd.doubleq_state(O, A, 1, 21)
+    q1 = [p.requires_grad_(True) for p in ref.params_from_state(st, "net_q1.net.")]
+    q2 = [p.requires_grad_(True) for p in ref.params_from_state(st, "net_q2.net.")]
+    obs, act, tgt = T(dd.uniform((B, O), 1, -2, 2)), T(dd.uniform((B, A), 2)), T(dd.uniform((B, 1), 3))
+    a, b = ref.twin_forward_ref(q1, q2, obs, act)
+    loss = torch.nn.functional.mse_loss(a, tgt) + torch.nn.functional.mse_loss(b, tgt)
+    full = torch.cat([g.reshape(-1) for g in torch.autograd.grad(loss, [*q1, *q2])]).numpy()
+    np.testing.assert_allclose(g0, full, rtol=1e-5, atol=1e-8)      # 1e-6..1e-5 relative
+
+
+# --------------------------------------------------------------------------- running statistics
+def _rms(rank, world):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pql_amd.utils.torch_util import RunningMeanStd
+    rms = RunningMeanStd(shape=(6,), device="cpu")
+    rms.pg = dist.group.WORLD
+    for step in range(3):
+        x = T(dd.uniform((32, 6), 100 + 10 * step + rank, -3, 5))   # this rank's env shard
+        rms.merge_batch(x.mean(0), x.var(0), x.shape[0])            # (batch moments come from a HIP launch on GPU)
+    return np.concatenate([rms.mean.numpy(), rms.var.numpy(), [rms.count]])
+
+
+def test_running_mean_std_merges_identically_on_every_rank():
+    from oracle import pql_ref_cpu as ref
+    a, b = run2(_rms)
+    assert np.array_equal(a, b)
+    single = ref.RunningMeanStdRef((6,))
+    for step in range(3):
+        for rank in range(2):
+            single.update(T(dd.uniform((32, 6), 100 + 10 * step + rank, -3, 5)))
+    np.testing.assert_allclose(a, np.concatenate([single.mean.numpy(), single.var.numpy(), [single.count]]), rtol=1e-6)
+
+
+# --------------------------------------------------------------------------- env / noise sharding (no process group needed)
+def test_env_shards_reproduce_slices_of_the_global_env():
+    from pql_amd.envs.synthetic import SyntheticVecEnv
+    full = SyntheticVecEnv(64, 5, 3, device="cpu", seed=42)
+    shards = [SyntheticVecEnv(32, 5, 3, device="cpu", seed=42, env_offset=off) for off in (0, 32)]
+    o = full.reset(); os_ = [s.reset() for s in shards]
+    assert torch.equal(o, torch.cat(os_))
+    act = T(dd.uniform((64, 3), 5))
+    for _ in range(3):
+        n, r, d, info = full.step(act)
+        parts = [s.step(act[i * 32:(i + 1) * 32]) for i, s in enumerate(shards)]
+        assert torch.equal(n, torch.cat([p[0] for p in parts]))
+        assert torch.equal(r, torch.cat([p[1] for p in parts])) and torch.equal(d, torch.cat([p[2] for p in parts]))
+        assert not info["TimeLimit.truncated"].any()
+    assert abs(float(o.mean())) < 0.2 and 0.8 < float(o.std()) < 1.2      # N(0,1) observations
+
+
+def test_mixed_noise_uses_global_env_index():
+    from pql_amd.utils.noise import add_mixed_normal_noise
+    std = torch.linspace(0.05, 0.8, 8)                                       # sigma of GLOBAL env e = linspace(...)[e]
+    for off in (0, 4):
+        torch.manual_seed(1); got = add_mixed_normal_noise(torch.zeros(4, 2), 0.8, 0.05, env_offset=off, total_envs=8)
+        torch.manual_seed(1); draw = torch.empty(4, 2).normal_()
+        assert torch.allclose(got, draw * std[off: off + 4].unsqueeze(1))
+    torch.manual_seed(2); whole = add_mixed_normal_noise(torch.zeros(8, 2), 0.8, 0.05)
+    torch.manual_seed(2); draw = torch.empty(8, 2).normal_()
+    assert torch.allclose(whole, draw * std.unsqueeze(1))                    # single-GPU form unchanged

@@ -169,3 +169,74 @@ def test_graph_replay_matches_eager(dev):
     assert outs[0][3] == outs[1][3] == 4
     for a, b in zip(outs[0][:3], outs[1][:3]):
         assert torch.equal(a, b)
+
+
+# --------------------------------------------------------------------------- DDPG (BASELINE cfg #1) + entry points
+def _ddpg_cfg(extra=()):
+    from pql_amd.utils.cfg import load_cfg
+    return load_cfg(["algo=ddpg_algo", "task.name=Toy", "num_envs=64", "algo.batch_size=256", "algo.memory_size=100000",
+                     "device=cuda:0", "sim_device=cuda:0", *extra])
+
+
+def test_ddpg_update_vs_oracle(dev):
+    """cfg #1 shapes (64 envs, obs 8, act 2, batch 256, replay 100k): three inner iterations of update_net with
+    injected samples/noise against the oracle's DDPGRef (un-clamped normalisation, critic step, actor step through
+    the updated critic, Polyak)."""
+    from oracle import pql_ref_cpu as ref
+    from pql_amd.algo.ddpg import AgentDDPG
+    from pql_amd.envs.synthetic import create_task_env
+    from pql_amd.replay.simple_replay import ReplayBuffer
+    cfg = _ddpg_cfg()
+    agent = AgentDDPG(create_task_env(cfg), cfg)
+    O, A, B, rows = 8, 2, 256, 3000
+    cst, ast = dd.doubleq_state(O, A, 1, 21), dd.mlp_state(O, A, 11)
+    agent.critic.load_state_dict(_sd(cst)); agent.critic_target.arena.data.copy_(agent.critic.arena.data)
+    agent.actor.load_state_dict(_sd(ast))
+    mean, var = T(dd.uniform((O,), 801, -0.5, 0.5)), T(dd.uniform((O,), 802, 0.5, 2.0))
+    agent.obs_rms.mean, agent.obs_rms.var = mean.to(dev), var.to(dev)
+    data = _fill(O, A, rows, 77)
+    memory = ReplayBuffer(100000, (O,), A, device=dev)
+    memory.add_to_buffer(tuple(t.to(dev) for t in data))
+    orc = ref.DDPGRef(O, A, ref.HyperRef(batch_size=B), 100000, ref.params_from_state(ast),
+                      ref.params_from_state(cst, "net_q1.net."), ref.params_from_state(cst, "net_q2.net."))
+    orc.ring.insert(*data); orc.norm = (mean, var, 1e-4)
+    for s in range(3):
+        idx, draw = T(dd.integers((B,), 40 + s, rows)), T(dd.uniform((B, A), 50 + s, -2, 2))
+        cl, al_ = orc.update_once(idx, draw)
+        agent.update_once(memory, indices=idx, noise=draw)
+        np.testing.assert_allclose(agent.closs[s % 5].item(), cl, rtol=2e-5)
+        np.testing.assert_allclose(agent.aloss[s % 5].item(), al_, rtol=2e-5, atol=1e-7)
+    lay = agent.critic.layout
+    for n, net in enumerate((orc.q1, orc.q2)):
+        for l in range(lay.n_layers):
+            np.testing.assert_allclose(lay.weight(agent.critic.arena.data, n, l).cpu().numpy(), net[2 * l].detach().numpy(),
+                                       rtol=1e-5, atol=1e-5)
+    for l in range(agent.actor.layout.n_layers):
+        np.testing.assert_allclose(agent.actor.layout.weight(agent.actor.arena.data, 0, l).cpu().numpy(),
+                                   orc.actor[2 * l].detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(lay.weight(agent.critic_target.arena.data, 1, 1).cpu().numpy(), orc.t2[2].numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_train_baselines_entry_point_cfg1(dev):
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_baselines", os.path.join(root, "scripts", "train_baselines.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    out = mod.main(_ddpg_cfg(["max_step=4000", "algo.update_times=8"]))
+    assert out["global_steps"] > 4000 and np.isfinite(out["train/critic_loss"]) and np.isfinite(out["train/actor_loss"])
+
+
+@pytest.mark.parametrize("distl", [False, True])
+def test_train_pql_entry_point(dev, distl):
+    """scripts/train_pql.py on a tiny config: the loop keeps the reference's counters and design ratios
+    (8 critic steps and 4 actor steps per env iteration) and finite losses."""
+    import importlib.util, os
+    from pql_amd.utils.cfg import load_cfg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_pql", os.path.join(root, "scripts", "train_pql.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    cfg = load_cfg(["task.name=Toy", "num_envs=64", "algo.batch_size=256", "algo.memory_size=20000", "algo.num_gpus=1",
+                    f"algo.distl={distl}", "max_step=6000", "algo.graph=True"])
+    out = mod.main(cfg)
+    iters = (out["global_steps"] - 64 * 32) // 64
+    assert out["critic_updates"] == 8 * iters and out["actor_updates"] == 4 * iters
