@@ -46,7 +46,7 @@ def main(cfg):
             logger.log(log_info, global_steps)
         if (cfg.max_step is not None and global_steps > cfg.max_step) or (cfg.max_step is None and time.time() - start > cfg.max_time):
             break
-    return dict(global_steps=global_steps, iters=iter_t + 1, **log_info)
+    return {**log_info, "global_steps": global_steps, "iters": iter_t + 1}
 
 
 if __name__ == "__main__":
