@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--hidden", default="512,512,256", help="BASELINE shape; the reference default is 512,256,128")
     ap.add_argument("--distl", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-streams", action="store_true", help="serialise V / P / rollout on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=24, help="V steps of the bounded CPU-oracle sample")
     ap.add_argument("--v-only", action="store_true", help="time free-running V-learner steps only")
@@ -75,7 +76,8 @@ def build_system(args, rank, world, device, pg):
     ov = [f"num_envs={args.num_envs}", f"task.name={args.task}", f"algo.batch_size={args.batch}",
           f"algo.memory_size={args.replay}", f"algo.nstep={args.nstep}", f"algo.distl={args.distl}",
           f"algo.v_learner_gpu={device.index}", f"algo.p_learner_gpu={device.index}", "algo.num_gpus=1",
-          f"algo.graph={not args.no_graph}", f"sim_device=cuda:{device.index}", f"device=cuda:{device.index}"]
+          f"algo.graph={not args.no_graph}", f"algo.streams={not args.no_streams}", f"sim_device=cuda:{device.index}",
+          f"device=cuda:{device.index}"]
     cfg = load_cfg(ov)
     cfg.algo.hidden_layers = hidden
     cfg.algo.reward_scale = 0.01   # preprocess_cfg's AllegroHand value (common.py:159-170)
@@ -130,12 +132,19 @@ class Schedule:
         k = self.k
         self.k += 1
         if not self.v_only and k % self.r_env == 0:
+            sim = torch.cuda.current_stream(self.device)          # rollout queue
+            if self.p.stream is not None:
+                sim.wait_stream(self.p.stream)                    # newest policy weights come from the P-learner's queue
+            self.actor.actor.arena.data.copy_(self.p.actor.arena.data)
             p_data, v_data, n = self.actor.explore_env(self.env, self.cfg.algo.horizon_len, random=False)
             self.global_steps += n
             rms = self.actor.obs_rms.get_states(self.device)
-            self.v.update(self.actor.actor, v_data, rms, 0)      # transitions + policy replica -> V-learner
-            self.p.update(self.v.critic, p_data, rms, 0)         # obs + critic replica -> P-learner
-            self.actor.actor.arena.data.copy_(self.p.actor.arena.data)   # newest policy -> rollout
+            self.p.critic_stream = self.v.stream
+            self.v.update(self.actor.actor, v_data, rms, 0)      # transitions + policy replica -> V-learner (its queue)
+            self.p.update(self.v.critic, p_data, rms, 0)         # obs + critic replica -> P-learner (its queue)
+            if self.v.stream is not None:                         # the rollout may not recycle these buffers early
+                sim.wait_stream(self.v.stream)
+                sim.wait_stream(self.p.stream)
         self.v.learn()
         if not self.v_only and k % self.r_p == self.r_p - 1:
             self.p.learn()
@@ -327,7 +336,7 @@ def main():
                                f"{args.replay} rows resident in HBM, batch {args.batch}, n-step {args.nstep}, "
                                f"{'DistributionalDoubleQ(51)' if args.distl else 'DoubleQ'} MLP {hidden}",
                    "schedule": "v_only" if args.v_only else "1 env-iteration : 4 P-steps : 8 V-steps",
-                   "graph": not args.no_graph, "parallelism": f"dp{world}" if world > 1 else "single"},
+                   "graph": not args.no_graph, "streams": not args.no_streams, "parallelism": f"dp{world}" if world > 1 else "single"},
         "p_grad_steps_per_s": 0.0 if args.v_only else value / int(cfg.algo.critic_actor_ratio),
         "env_steps_per_s": 0.0 if args.v_only else value / int(cfg.algo.critic_sample_ratio) * args.num_envs,
         "gflop_per_v_step": f_v / 1e9, "gflop_per_p_step": f_p / 1e9,

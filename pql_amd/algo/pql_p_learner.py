@@ -11,6 +11,7 @@ learn()  (reference :47-64)  ->  one launch sequence
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import time
 from copy import deepcopy
@@ -18,7 +19,7 @@ from copy import deepcopy
 import torch
 
 from pql_amd import _lib as L
-from pql_amd.algo.pql_v_learner import LOSS_RING, _AdamState, _cfg_get, apply_optimizer, resident_norm
+from pql_amd.algo.pql_v_learner import LOSS_RING, LaggedLoss, _AdamState, _cfg_get, apply_optimizer, resident_norm
 from pql_amd.models import model_name_to_path
 from pql_amd.models.mlp import default_splits, output_view
 from pql_amd.replay.simple_replay import RecordRing, _obs_width, ring_plan
@@ -55,10 +56,12 @@ class PQLPLearner:
 
         self.loss_tracker = Tracker(LOSS_RING)
         self.loss_ring = torch.zeros(LOSS_RING, dtype=torch.float32, device=self.device)
+        self._lagged = LaggedLoss(self.loss_ring)
         self.update_count = 0
         self.normalize_tuple = None
         self.sleep_time = 0.01
         self.use_graph = bool(_cfg_get(algo, "graph", False))
+        self.stream = torch.cuda.Stream(self.device) if bool(_cfg_get(algo, "streams", False)) else None
         self._ws = None
         self._graph = None
         self._graph_key = None
@@ -70,6 +73,9 @@ class PQLPLearner:
 
     def start(self):
         return self.actor, self.update_count, self.loss_tracker.mean()
+
+    def _on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def _workspace(self, B):
         if self._ws is not None and self._ws["B"] == B:
@@ -135,7 +141,7 @@ class PQLPLearner:
         if self.critic is None:
             return self.sleep_time
         B = int(self.cfg.algo.batch_size)
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), self._on_stream():
             ws = self._workspace(B)
             if indices is not None:
                 self._step_kernels(ws, indices.to(self.device, torch.int64).contiguous())
@@ -170,12 +176,14 @@ class PQLPLearner:
         self._graph, self._graph_key = g, key
 
     def loss_mean(self):
-        vals = self.loss_ring.tolist()
-        n = min(self.update_count, LOSS_RING)
+        """Exact mean of the last 5 losses (Tracker(5).mean(), zero-filled before 5 steps); synchronises."""
+        with torch.cuda.device(self.device), self._on_stream():
+            vals = self.loss_ring.tolist()
+        m = LaggedLoss.mean_of(vals, self.update_count)
         self.loss_tracker = Tracker(LOSS_RING)
-        for t in range(self.update_count - n, self.update_count):
+        for t in range(self.update_count - min(self.update_count, LOSS_RING), self.update_count):
             self.loss_tracker.update(vals[t % LOSS_RING])
-        return self.loss_tracker.mean()
+        return m
 
     def set_critic(self, critic):
         """Adopt new critic weights into a resident replica (flat arena copy; peer copy over xGMI when the
@@ -190,15 +198,25 @@ class PQLPLearner:
 
     @torch.no_grad()
     def update(self, critic, obs, normalize_tuple, sleep_time):
-        self.set_critic(critic)
-        self.sleep_time = sleep_time
-        self.normalize_tuple = resident_norm(self, normalize_tuple)
-        obs = obs.reshape(-1, self.ring.O).to(self.device, torch.float32).contiguous()
-        self.add_capacity = obs.shape[0]
-        segs, self.next_p, self.if_full, self.cur_capacity = ring_plan(self.next_p, self.if_full, self.memory_size,
-                                                                       obs.shape[0])
-        self.ring.insert_segments(segs, obs)
-        return self.actor, self.loss_mean(), self.update_count
+        with torch.cuda.device(self.device), self._on_stream():
+            if self.stream is not None:
+                self.stream.wait_stream(torch.cuda.default_stream(self.device) if getattr(self, "producer_stream", None) is None
+                                        else self.producer_stream)
+                critic_stream = getattr(self, "critic_stream", None)
+                if critic_stream is not None:
+                    self.stream.wait_stream(critic_stream)   # newest critic weights are produced on the V-learner's stream
+                if obs.is_cuda:
+                    obs.record_stream(self.stream)
+            self.set_critic(critic)
+            self.sleep_time = sleep_time
+            self.normalize_tuple = resident_norm(self, normalize_tuple)
+            obs = obs.reshape(-1, self.ring.O).to(self.device, torch.float32).contiguous()
+            self.add_capacity = obs.shape[0]
+            segs, self.next_p, self.if_full, self.cur_capacity = ring_plan(self.next_p, self.if_full, self.memory_size,
+                                                                           obs.shape[0])
+            self.ring.insert_segments(segs, obs)
+            loss = self._lagged.poll(self.update_count)
+        return self.actor, loss, self.update_count
 
 
 def asyn_p_learner(learner, cfg, stop_event=None):

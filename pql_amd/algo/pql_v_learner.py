@@ -14,6 +14,7 @@ is captured once into a hipGraph (through torch.cuda.CUDAGraph) and replayed.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import time
 from copy import deepcopy
@@ -55,6 +56,36 @@ def apply_optimizer(arena, grads, st: _AdamState, target, lr, max_grad_norm, tau
                                          float(max_grad_norm) if max_grad_norm is not None else 0.0,
                                          float(lr), 0.9, 0.999, 1e-8, 1e-2, float(tau), L.ptr(st.step), L.ptr(st.gnorm),
                                          L.ptr(st.scratch), L.stream(device)))
+
+
+class LaggedLoss:
+    """Mean of the last LOSS_RING losses without stalling the stream: each call enqueues an async copy of the
+    device ring to pinned host memory and returns the value of the last copy that has completed (one hand-off
+    behind).  Replaces the reference's per-step `loss.item()` + Tracker(5) (pql_v_learner.py:111)."""
+
+    def __init__(self, ring: torch.Tensor):
+        self.ring = ring
+        self.host = torch.zeros(ring.numel(), dtype=torch.float32).pin_memory()
+        self.event = None
+        self.count_at_copy = 0
+        self.value = 0.0
+
+    @staticmethod
+    def mean_of(vals, count):
+        n = min(count, LOSS_RING)
+        window = [vals[t % LOSS_RING] for t in range(count - n, count)]
+        return float(sum(window) / LOSS_RING)   # Tracker(5) is zero-filled: always divides by its length
+
+    def poll(self, count):
+        if self.event is not None and self.event.query():
+            self.value = self.mean_of(self.host.tolist(), self.count_at_copy)
+            self.event = None
+        if self.event is None:
+            self.host.copy_(self.ring, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+            self.count_at_copy = count
+        return self.value
 
 
 def resident_norm(owner, normalize_tuple):
@@ -105,10 +136,14 @@ class PQLVLearner:
                                    device=self.device)
         self.loss_tracker = Tracker(LOSS_RING)
         self.loss_ring = torch.zeros(LOSS_RING, dtype=torch.float32, device=self.device)
+        self._lagged = LaggedLoss(self.loss_ring)
         self.update_count = 0
         self.normalize_tuple = None
         self.sleep_time = 0
         self.use_graph = bool(_cfg_get(algo, "graph", False))
+        # own HIP stream: the MI355X form of the reference's separate learner process (Ray actor).  V-learner,
+        # P-learner and rollout queues then overlap on the GPU; hand-offs are event-fenced in update().
+        self.stream = torch.cuda.Stream(self.device) if bool(_cfg_get(algo, "streams", False)) else None
         self._ws = None
         self._graph = None
         self._graph_key = None
@@ -116,6 +151,9 @@ class PQLVLearner:
     # ------------------------------------------------------------------------------------------
     def start(self):
         return self.critic, self.update_count, self.loss_tracker.mean()
+
+    def _on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def _workspace(self, B):
         if self._ws is not None and self._ws["B"] == B:
@@ -203,7 +241,7 @@ class PQLVLearner:
         if self.actor is None:
             return self.sleep_time
         B = int(self.cfg.algo.batch_size)
-        with torch.cuda.device(self.device):
+        with torch.cuda.device(self.device), self._on_stream():
             ws = self._workspace(B)
             if indices is not None or noise is not None:
                 idx = (indices.to(self.device, torch.int64).contiguous() if indices is not None
@@ -251,14 +289,14 @@ class PQLVLearner:
 
     # ------------------------------------------------------------------------------------------
     def loss_mean(self):
-        """Mean of the last 5 critic losses (Tracker(5).mean(), zero-filled before 5 steps) -- one host sync."""
-        vals = self.loss_ring.tolist()
-        n = min(self.update_count, LOSS_RING)
-        # ring slot of step t (1-based counter after increment happens later in the step) is (t-1) % 5
+        """Exact mean of the last 5 losses (Tracker(5).mean(), zero-filled before 5 steps); synchronises."""
+        with torch.cuda.device(self.device), self._on_stream():
+            vals = self.loss_ring.tolist()
+        m = LaggedLoss.mean_of(vals, self.update_count)
         self.loss_tracker = Tracker(LOSS_RING)
-        for t in range(self.update_count - n, self.update_count):
+        for t in range(self.update_count - min(self.update_count, LOSS_RING), self.update_count):
             self.loss_tracker.update(vals[t % LOSS_RING])
-        return self.loss_tracker.mean()
+        return m
 
     def set_actor(self, actor):
         """Adopt new policy weights.  A pql_amd actor on another GPU is copied arena-to-arena (peer copy
@@ -270,11 +308,19 @@ class PQLVLearner:
 
     @torch.no_grad()
     def update(self, actor, trajectory, normalize_tuple, sleep_time):
-        self.set_actor(actor)
-        self.memory.add_to_buffer(trajectory)
-        self.normalize_tuple = resident_norm(self, normalize_tuple)
+        with torch.cuda.device(self.device), self._on_stream():
+            if self.stream is not None:   # fence: the producer's work (rollout stream) must be visible first
+                self.stream.wait_stream(torch.cuda.default_stream(self.device) if getattr(self, "producer_stream", None) is None
+                                        else self.producer_stream)
+                for t in trajectory:
+                    if t.is_cuda:
+                        t.record_stream(self.stream)
+            self.set_actor(actor)
+            self.memory.add_to_buffer(trajectory)
+            self.normalize_tuple = resident_norm(self, normalize_tuple)
+            loss = self._lagged.poll(self.update_count)
         self.sleep_time = sleep_time
-        return self.critic, self.loss_mean(), self.update_count
+        return self.critic, loss, self.update_count
 
 
 def asyn_v_learner(learner, cfg, stop_event=None):

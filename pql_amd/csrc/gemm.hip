@@ -201,8 +201,12 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
+#if defined(PQLK_PROBE_NOLOAD)   // tuning probe only: recompute on stage 0, no global/LDS-store/barrier traffic
+      const int stage = 0;
+#else
       const int stage = kt & 1;
       if (kt + 1 < nk) gload(kt + 1);
+#endif
       const float* sa = smem + stage * S::STAGE;
       const float* sb = sa + S::A_FLOATS;
 
@@ -214,6 +218,16 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
 #pragma unroll
       for (int k8 = 0; k8 < 4; ++k8) {
         float af[MI][4], bf[NJ][4];
+#if defined(PQLK_PROBE_NOLDS)   // tuning probe only: operands from registers, pure MFMA issue rate
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { af[i][t] = __int_as_float(lane + kt + t + i); asm volatile("" : "+v"(af[i][t])); }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { bf[j][t] = __int_as_float(lane - kt + t + j); asm volatile("" : "+v"(bf[j][t])); }
+#else
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
           if (MODE == MODE_DW) {
@@ -234,6 +248,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
             for (int t = 0; t < 4; ++t) bf[j][t] = sb[(8 * k8 + 4 * h + t) * (BN + 4) + wn + 32 * j + r];
           }
         }
+#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -243,8 +258,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
       }
 
+#if !defined(PQLK_PROBE_NOLOAD)
       if (kt + 1 < nk) sstore(stage ^ 1);
       __syncthreads();
+#endif
     }
   }
 
