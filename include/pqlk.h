@@ -232,9 +232,10 @@ int pqlk_clip_adamw_polyak(float* p, float* g, float* m, float* v, float* target
 int pqlk_polyak(float* target, const float* cur, int64_t n, float tau, pqlk_stream_t stream);
 
 /* RunningMeanStd.update batch moments (torch_util.py:77-81): mean and UNBIASED variance over rows of
- * x (N, ldx) for `cols` columns -> mean_out, var_out (cols).  The Chan merge (:87-103) stays on host. */
+ * x (N, ldx) for `cols` columns -> mean_out, var_out (cols).  The Chan merge (:87-103) stays on host.
+ * scratch: >= 64 * cols * 3 floats (per-chunk count / mean / M2). */
 int pqlk_batch_moments(const float* x, int64_t ldx, int64_t n, int32_t cols, float* mean_out, float* var_out,
-                       pqlk_stream_t stream);
+                       float* scratch, pqlk_stream_t stream);
 
 #ifdef __cplusplus
 }

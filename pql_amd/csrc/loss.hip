@@ -44,14 +44,8 @@ __global__ __launch_bounds__(256) void k_td_mse(const float* __restrict__ q, con
     const float y = rew[i] + ((1.f - done[i]) * gamma_n) * tq;  // r + (1-d)*gamma^n*minQ'  (:105)
     const float d1 = q[i * ld] - y, d2 = q[(b + i) * ld] - y;
     acc += d1 * d1 + d2 * d2;
-    float* r1 = dy + i * ld;
-    float* r2 = dy + (b + i) * ld;
-    r1[0] = two_over_b * d1;
-    r2[0] = two_over_b * d2;
-    for (int c = 1; c < ld; ++c) {
-      r1[c] = 0.f;
-      r2[c] = 0.f;
-    }
+    dy[i * ld] = two_over_b * d1;
+    dy[(b + i) * ld] = two_over_b * d2;
   }
   const float s = block_sum_256(acc);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
@@ -222,14 +216,8 @@ __global__ __launch_bounds__(256) void k_dpg_scalar(const float* __restrict__ q,
     acc += fminf(a, c);
     const float g1 = a < c ? g : (a == c ? 0.5f * g : 0.f);
     const float g2 = c < a ? g : (a == c ? 0.5f * g : 0.f);
-    float* r1 = dy + i * ld;
-    float* r2 = dy + (b + i) * ld;
-    r1[0] = g1;
-    r2[0] = g2;
-    for (int col = 1; col < ld; ++col) {
-      r1[col] = 0.f;
-      r2[col] = 0.f;
-    }
+    dy[i * ld] = g1;
+    dy[(b + i) * ld] = g2;
   }
   const float s = block_sum_256(acc);
   if (threadIdx.x == 0) part[blockIdx.x] = s;

@@ -134,24 +134,30 @@ extern "C" int pqlk_polyak(float* target, const float* cur, int64_t n, float tau
 }
 
 // ------------------------------------------------------------------------------------------------
-// batch mean / unbiased variance per column.  Block = 32 columns x 8 row-lanes, two passes.
-__global__ __launch_bounds__(256) void k_batch_moments(const float* __restrict__ x, int64_t ldx, int64_t n, int cols,
-                                                       float* __restrict__ mean_out, float* __restrict__ var_out) {
+// batch mean / unbiased variance per column, two stages so the whole chip streams the (N, cols) block:
+//   stage 1: grid (col tiles of 32, row chunks): per chunk mean and M2 = sum (x - chunk_mean)^2 (two passes over
+//            rows the block just touched, L2-resident);  stage 2: Chan merge of the chunk moments in fixed order.
+#define MOM_CHUNKS 64
+__global__ __launch_bounds__(256) void k_moments_stage1(const float* __restrict__ x, int64_t ldx, int64_t n, int cols,
+                                                        int64_t rows_per_chunk, float* __restrict__ part) {
   __shared__ float sh[8][33];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + cx;
+  const int64_t r0 = blockIdx.y * rows_per_chunk;
+  const int64_t r1 = r0 + rows_per_chunk < n ? r0 + rows_per_chunk : n;
+  const float cnt = (float)(r1 > r0 ? r1 - r0 : 0);
   float s = 0.f;
   if (col < cols)
-    for (int64_t r = ry; r < n; r += 8) s += x[r * ldx + col];
+    for (int64_t r = r0 + ry; r < r1; r += 8) s += x[r * ldx + col];
   sh[ry][cx] = s;
   __syncthreads();
   float mean = 0.f;
   for (int k = 0; k < 8; ++k) mean += sh[k][cx];
-  mean /= (float)n;
+  mean = cnt > 0.f ? mean / cnt : 0.f;
   __syncthreads();
   float q = 0.f;
   if (col < cols)
-    for (int64_t r = ry; r < n; r += 8) {
+    for (int64_t r = r0 + ry; r < r1; r += 8) {
       const float d = x[r * ldx + col] - mean;
       q += d * d;
     }
@@ -160,17 +166,41 @@ __global__ __launch_bounds__(256) void k_batch_moments(const float* __restrict__
   if (ry == 0 && col < cols) {
     float t = 0.f;
     for (int k = 0; k < 8; ++k) t += sh[k][cx];
-    mean_out[col] = mean;
-    var_out[col] = t / (float)(n - 1);
+    float* o = part + ((int64_t)blockIdx.y * cols + col) * 3;
+    o[0] = cnt; o[1] = mean; o[2] = t;
   }
 }
 
+__global__ __launch_bounds__(256) void k_moments_stage2(const float* __restrict__ part, int chunks, int cols, int64_t n,
+                                                        float* __restrict__ mean_out, float* __restrict__ var_out) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= cols) return;
+  float cnt = 0.f, mean = 0.f, m2 = 0.f;
+  for (int c = 0; c < chunks; ++c) {
+    const float* o = part + ((int64_t)c * cols + col) * 3;
+    const float nb = o[0];
+    if (nb <= 0.f) continue;
+    const float delta = o[1] - mean, tot = cnt + nb;
+    mean += delta * nb / tot;
+    m2 += o[2] + delta * delta * cnt * nb / tot;
+    cnt = tot;
+  }
+  mean_out[col] = mean;
+  var_out[col] = m2 / (float)(n - 1);
+}
+
 extern "C" int pqlk_batch_moments(const float* x, int64_t ldx, int64_t n, int32_t cols, float* mean_out, float* var_out,
-                                  pqlk_stream_t stream) {
-  PQLK_REQUIRE(x && mean_out && var_out, PQLK_E_NULL);
+                                  float* scratch, pqlk_stream_t stream) {
+  PQLK_REQUIRE(x && mean_out && var_out && scratch, PQLK_E_NULL);
   PQLK_REQUIRE(n >= 2 && cols > 0 && ldx >= cols, PQLK_E_SHAPE);
-  hipLaunchKernelGGL(k_batch_moments, dim3((cols + 31) / 32), dim3(256), 0, pqlk_s(stream), x, ldx, n, (int)cols, mean_out,
-                     var_out);
+  int chunks = (int)((n + 63) / 64);
+  if (chunks > MOM_CHUNKS) chunks = MOM_CHUNKS;
+  const int64_t rows_per_chunk = (n + chunks - 1) / chunks;
+  hipLaunchKernelGGL(k_moments_stage1, dim3((cols + 31) / 32, chunks), dim3(256), 0, pqlk_s(stream), x, ldx, n, (int)cols,
+                     rows_per_chunk, scratch);
+  PQLK_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_moments_stage2, dim3((cols + 255) / 256), dim3(256), 0, pqlk_s(stream), scratch, chunks, (int)cols, n,
+                     mean_out, var_out);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }

@@ -120,11 +120,13 @@ extern "C" int pqlk_replay_gather(const PqlReplayDesc* ring, const int64_t* idx,
 
 // ------------------------------------------------------------------------------------------------
 // fused gather: sample + normalise (+-5 clamp) + concat into the padded GEMM input tiles.
-__device__ __forceinline__ float norm1(float x, float mean, float var, float eps, int clamp5) {
-  float y = (x - mean) / sqrtf(var + eps);  // IEEE div/sqrt: bit-identical to torch CPU fp32
+__device__ __forceinline__ float norm1(float x, float mean, float sd, int clamp5) {
+  float y = (x - mean) / sd;  // IEEE division: bit-identical to (x-mean)/sqrt(var+eps) evaluated by torch
   if (clamp5) y = fminf(fmaxf(y, -5.f), 5.f);
   return y;
 }
+
+#define GATHER_MAX_OBS 1024
 
 template <bool HAS_NORM>
 __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __restrict__ records, RecLayout L,
@@ -134,6 +136,17 @@ __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __rest
                                                              float* __restrict__ xn_sa, float* __restrict__ xn_obs,
                                                              int64_t ld_o, float* __restrict__ o_rew,
                                                              float* __restrict__ o_done) {
+  // per-column mean and sd = sqrt(var + eps) (correctly rounded sqrtf) staged once per block: the per-element work
+  // is then one subtract and one IEEE divide instead of a divide AND a square root
+  __shared__ float s_mean[HAS_NORM ? GATHER_MAX_OBS : 1];
+  __shared__ float s_sd[HAS_NORM ? GATHER_MAX_OBS : 1];
+  if (HAS_NORM) {
+    for (int c = threadIdx.x; c < L.O; c += 256) {
+      s_mean[c] = mean[c];
+      s_sd[c] = sqrtf(var[c] + eps);
+    }
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -155,7 +168,7 @@ __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __rest
         if (HAS_NORM) {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
-            if (c + j < L.O) e[j] = norm1(e[j], mean[c + j], var[c + j], eps, clamp5);
+            if (c + j < L.O) e[j] = norm1(e[j], s_mean[c + j], s_sd[c + j], clamp5);
         }
         if (L.A < 0) {  // obs-only ring: the sample IS the learner's obs batch
 #pragma unroll
@@ -175,7 +188,7 @@ __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __rest
           if (HAS_NORM) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              if (cc + j < L.O) e[j] = norm1(e[j], mean[cc + j], var[cc + j], eps, clamp5);
+              if (cc + j < L.O) e[j] = norm1(e[j], s_mean[cc + j], s_sd[cc + j], clamp5);
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j)
@@ -218,6 +231,7 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
   RecLayout L = rec_layout(ring->obs_dim, ring->act_dim);
   PQLK_REQUIRE(ring->rec_ld == L.ld, PQLK_E_SHAPE);
   PQLK_REQUIRE((mean == nullptr) == (var == nullptr), PQLK_E_NULL);
+  if (mean) PQLK_REQUIRE(L.O <= GATHER_MAX_OBS, PQLK_E_UNSUPPORTED);
   if (x_sa || xn_sa) PQLK_REQUIRE(ld_sa % 32 == 0 && ld_sa >= L.O + (L.A < 0 ? 0 : L.A), PQLK_E_ALIGN);
   if (xn_obs) PQLK_REQUIRE(ld_o % 32 == 0 && ld_o >= L.O, PQLK_E_ALIGN);
   if (L.A < 0) PQLK_REQUIRE(xn_sa == nullptr, PQLK_E_UNSUPPORTED);

@@ -1,0 +1,221 @@
+// VALU kernels for the skinny last layer of an MLP (out features <= 16: the critic's scalar Q head, the
+// actor's 16-21 -> here <=16 action head).  Reference ops: the final nn.Linear of create_simple_mlp
+// (pql/models/mlp.py:15-24) and its autograd.  A 32x32 MFMA tile would waste >= 50 % (N=16) to 97 % (N=1) of its
+// columns and a whole launch of prologue/epilogue; these are HBM-bound streaming passes over the (B, K) hidden
+// activations instead: one wave per batch row, 16-B lane accesses, the (N, K) weight block staged in LDS.
+#pragma once
+#include "pqlk_common.h"
+
+#define SKINNY_MAX_N 16
+#define SKINNY_MAX_K 1024
+
+struct SkinnyP {
+  const float* X;     // (groups, M, ldx) hidden activations (input of the layer); sX = 0 when shared
+  const float* W;     // (N, ldk) per group
+  const float* bias;  // (ld(N)) per group
+  float* C;           // fwd: (groups, M, ldc) output;  dx: (groups, M, ldk) dH
+  const float* dY;    // dx/dw: (groups, M, ldy)
+  const float* draw;  // fwd TANH_NOISE: (M, N) contiguous
+  float* C2;          // fwd: optional second destination (group 0)
+  float* dW;          // dw: slab base of W block (per group/split)
+  float* dB;          // dw: slab base of bias block
+  int M, N, K;        // rows, out features, padded in features (multiple of 32)
+  int ldx, ldk, ldc, ldy, ldc2;
+  long long sX, sW, sBias, sC, sY, sSplit;
+  int epi;            // fwd: EPI_NONE / EPI_TANH / EPI_TANH_NOISE ; dx: EPI_DELU / EPI_NONE
+  int splits, rows_per_split;
+  float noise_std, noise_clip;
+};
+
+enum { SK_EPI_NONE = 0, SK_EPI_TANH = 2, SK_EPI_TANH_NOISE = 3, SK_EPI_DELU = 4 };
+
+// ---------------------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(256) void k_skinny_fwd(SkinnyP p) {
+  extern __shared__ __attribute__((aligned(16))) float w_lds[];  // (N, K)
+  const int g = blockIdx.y;
+  const float* W = p.W + (long long)g * p.sW;
+  const int kq = p.K >> 2;  // float4 chunks per row
+  for (int i = threadIdx.x; i < p.N * kq; i += 256) {
+    const int n = i / kq, q = i % kq;
+    reinterpret_cast<float4*>(w_lds)[i] = *reinterpret_cast<const float4*>(W + (long long)n * p.ldk + 4 * q);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const float* X = p.X + (long long)g * p.sX;
+  float* C = p.C + (long long)g * p.sC;
+  const float bv = lane < p.N ? p.bias[(long long)g * p.sBias + lane] : 0.f;
+  const int nwaves = gridDim.x * 4;
+  for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < p.M; m += nwaves) {
+    float4 h[SKINNY_MAX_K / 256];
+#pragma unroll
+    for (int c = 0; c < SKINNY_MAX_K / 256; ++c) {
+      const int q = lane + 64 * c;
+      h[c] = q < kq ? *reinterpret_cast<const float4*>(X + (long long)m * p.ldx + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float mine = 0.f;
+    for (int n = 0; n < p.N; ++n) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < SKINNY_MAX_K / 256; ++c) {
+        const int q = lane + 64 * c;
+        if (q < kq) {
+          const float4 w = reinterpret_cast<const float4*>(w_lds)[n * kq + q];
+          s += h[c].x * w.x + h[c].y * w.y + h[c].z * w.z + h[c].w * w.w;
+        }
+      }
+      s = wave_sum(s);
+      if (lane == n) mine = s;
+    }
+    if (lane < p.ldc) {
+      float v = 0.f;
+      if (lane < p.N) {
+        v = mine + bv;
+        if (p.epi == SK_EPI_TANH) v = tanhf(v);
+        else if (p.epi == SK_EPI_TANH_NOISE) {
+          v = tanhf(v);
+          float nz = p.noise_std * p.draw[(long long)m * p.N + lane];
+          nz = fminf(fmaxf(nz, -p.noise_clip), p.noise_clip);
+          v = fminf(fmaxf(v + nz, -1.f), 1.f);
+        }
+        if (p.C2 && g == 0) p.C2[(long long)m * p.ldc2 + lane] = v;
+      }
+      C[(long long)m * p.ldc + lane] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- dX (+ ELU')
+__global__ __launch_bounds__(256) void k_skinny_dx(SkinnyP p) {
+  extern __shared__ __attribute__((aligned(16))) float w_lds[];  // (N, K)
+  const int g = blockIdx.y;
+  const float* W = p.W + (long long)g * p.sW;
+  const int kq = p.K >> 2;
+  for (int i = threadIdx.x; i < p.N * kq; i += 256) {
+    const int n = i / kq, q = i % kq;
+    reinterpret_cast<float4*>(w_lds)[i] = *reinterpret_cast<const float4*>(W + (long long)n * p.ldk + 4 * q);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const float* X = p.X + (long long)g * p.sX;
+  const float* dY = p.dY + (long long)g * p.sY;
+  float* C = p.C + (long long)g * p.sC;
+  const int nwaves = gridDim.x * 4;
+  for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < p.M; m += nwaves) {
+    const float dyl = lane < p.N ? dY[(long long)m * p.ldy + lane] : 0.f;
+    float dn[SKINNY_MAX_N];  // dY row broadcast to every lane (all lanes active here)
+#pragma unroll
+    for (int n = 0; n < SKINNY_MAX_N; ++n) dn[n] = __shfl(dyl, n, 64);
+#pragma unroll
+    for (int c = 0; c < SKINNY_MAX_K / 256; ++c) {
+      const int q = lane + 64 * c;
+      if (q < kq) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int n = 0; n < SKINNY_MAX_N; ++n) {
+          if (n < p.N) {
+            const float4 w = reinterpret_cast<const float4*>(w_lds)[n * kq + q];
+            a.x += dn[n] * w.x; a.y += dn[n] * w.y; a.z += dn[n] * w.z; a.w += dn[n] * w.w;
+          }
+        }
+        if (p.epi == SK_EPI_DELU) {
+          const float4 hv = *reinterpret_cast<const float4*>(X + (long long)m * p.ldx + 4 * q);
+          a.x = hv.x > 0.f ? a.x : a.x * (hv.x + 1.f);
+          a.y = hv.y > 0.f ? a.y : a.y * (hv.y + 1.f);
+          a.z = hv.z > 0.f ? a.z : a.z * (hv.z + 1.f);
+          a.w = hv.w > 0.f ? a.w : a.w * (hv.w + 1.f);
+        }
+        *reinterpret_cast<float4*>(C + (long long)m * p.ldk + 4 * q) = a;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- dW, db (split-batch slabs)
+// grid = (ceil(K/64), splits, groups); block = 64 columns x 4 row-lanes.
+__global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
+  __shared__ float dy_lds[128][SKINNY_MAX_N + 1];
+  __shared__ float red[4][64][SKINNY_MAX_N + 1];
+  const int g = blockIdx.z, split = blockIdx.y;
+  const int cx = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const float* X = p.X + (long long)g * p.sX;
+  const float* dY = p.dY + (long long)g * p.sY;
+  const int m_beg = split * p.rows_per_split;
+  const int m_end = min(p.M, m_beg + p.rows_per_split);
+  float acc[SKINNY_MAX_N];
+#pragma unroll
+  for (int n = 0; n < SKINNY_MAX_N; ++n) acc[n] = 0.f;
+  float dbacc = 0.f;
+  for (int m0 = m_beg; m0 < m_end; m0 += 128) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 128 * p.N; i += 256) {
+      const int r = i / p.N, n = i % p.N;
+      dy_lds[r][n] = (m0 + r < m_end) ? dY[(long long)(m0 + r) * p.ldy + n] : 0.f;
+    }
+    __syncthreads();
+    const int rows = min(128, m_end - m0);
+    for (int r = rl; r < rows; r += 4) {
+      const float hv = col < p.K ? X[(long long)(m0 + r) * p.ldx + col] : 0.f;
+#pragma unroll
+      for (int n = 0; n < SKINNY_MAX_N; ++n)
+        if (n < p.N) acc[n] += dy_lds[r][n] * hv;
+      if (blockIdx.x == 0 && cx < p.N) dbacc += dy_lds[r][cx];
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < SKINNY_MAX_N; ++n) red[rl][cx][n] = acc[n];
+  red[rl][cx][SKINNY_MAX_N] = dbacc;
+  __syncthreads();
+  if (rl == 0) {
+    float* dW = p.dW + (long long)g * p.sW + (long long)split * p.sSplit;
+    if (col < p.K) {
+      for (int n = 0; n < p.N; ++n)
+        dW[(long long)n * p.ldk + col] = ((red[0][cx][n] + red[1][cx][n]) + red[2][cx][n]) + red[3][cx][n];
+    }
+    if (blockIdx.x == 0 && cx < p.ldc) {  // ldc = pqlk_ld(N): zero the bias pad
+      float* dB = p.dB + (long long)g * p.sBias + (long long)split * p.sSplit;
+      const int S = SKINNY_MAX_N;
+      dB[cx] = cx < p.N ? ((red[0][cx][S] + red[1][cx][S]) + red[2][cx][S]) + red[3][cx][S] : 0.f;
+    }
+  }
+}
+
+static inline bool skinny_ok(int n_out, int k_padded) { return n_out <= SKINNY_MAX_N && k_padded <= SKINNY_MAX_K; }
+
+static int launch_skinny_fwd(const SkinnyP& p, int groups, hipStream_t st) {
+  int blocks = (p.M + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  const size_t sh = (size_t)p.N * p.K * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skinny_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       SKINNY_MAX_N * SKINNY_MAX_K * 4);
+    if (e != hipSuccess) return -(int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_skinny_fwd, dim3(blocks, groups), dim3(256), sh, st, p);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}
+
+static int launch_skinny_dx(const SkinnyP& p, int groups, hipStream_t st) {
+  int blocks = (p.M + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  const size_t sh = (size_t)p.N * p.K * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skinny_dx), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       SKINNY_MAX_N * SKINNY_MAX_K * 4);
+    if (e != hipSuccess) return -(int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_skinny_dx, dim3(blocks, groups), dim3(256), sh, st, p);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}
+
+static int launch_skinny_dw(const SkinnyP& p, int groups, hipStream_t st) {
+  hipLaunchKernelGGL(k_skinny_dw, dim3((p.K + 63) / 64, p.splits, groups), dim3(256), 0, st, p);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}

@@ -36,9 +36,11 @@ class RunningMeanStd:
         bm = torch.empty(cols, dtype=torch.float32, device=x.device)
         bv = torch.empty(cols, dtype=torch.float32, device=x.device)
         x = x.contiguous()
+        if getattr(self, "_scratch", None) is None or self._scratch.numel() < 64 * cols * 3 or self._scratch.device != x.device:
+            self._scratch = torch.empty(64 * cols * 3, dtype=torch.float32, device=x.device)
         with torch.cuda.device(x.device):
             L.check(L.lib.pqlk_batch_moments(L.ptr(x), x.stride(0), x.shape[0], cols, L.ptr(bm), L.ptr(bv),
-                                             L.stream(x.device)))
+                                             L.ptr(self._scratch), L.stream(x.device)))
         return bm.view(self.mean.shape), bv.view(self.mean.shape)
 
     def update(self, x):

@@ -316,7 +316,8 @@ def test_td_mse_loss(dev, ref, B):
     loss = torch.nn.functional.mse_loss(qr[0], y) + torch.nn.functional.mse_loss(qr[1], y)
     loss.backward()
     ld = 32
-    dy = torch.full((2, B, ld), 5.0, device=dev); lo = torch.zeros(1, device=dev); scr = torch.zeros(2048, device=dev)
+    # scalar heads write column 0 only: the dy buffer is allocated zeroed once and its pads are never dirtied
+    dy = torch.zeros((2, B, ld), device=dev); lo = torch.zeros(1, device=dev); scr = torch.zeros(2048, device=dev)
     qd, qtd, rd, dd_ = _pad(q, ld).to(dev), _pad(qt, ld).to(dev), rew.to(dev), done.to(dev)
     L.check(L.lib.pqlk_td_mse_loss(L.ptr(qd), L.ptr(qtd), ld, L.ptr(rd),
                                    L.ptr(dd_), gn, B, L.ptr(dy), L.ptr(lo), None, 0, L.ptr(scr), L.stream(dev)))
@@ -365,7 +366,8 @@ def test_dpg_loss(dev, K):
         e = [(torch.softmax(qr[i], 1) * z).sum(1) for i in range(2)]
         loss = -torch.min(e[0], e[1]).mean()
     loss.backward()
-    dy = torch.full((2, B, ld), 5.0, device=dev); lo = torch.zeros(1, device=dev); scr = torch.zeros(2048, device=dev)
+    dy = (torch.zeros if K == 1 else lambda *a, **k: torch.full(*a, 5.0, **k))((2, B, ld), device=dev)
+    lo = torch.zeros(1, device=dev); scr = torch.zeros(2048, device=dev)
     qd = _pad(q, ld).to(dev); zd = z.to(dev) if K > 1 else None
     L.check(L.lib.pqlk_dpg_loss(L.ptr(qd), ld, K, L.ptr(zd), B, L.ptr(dy), L.ptr(lo), None, 0,
                                 L.ptr(scr), L.stream(dev)))
