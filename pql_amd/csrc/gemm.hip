@@ -477,7 +477,7 @@ extern "C" int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const 
       p.noise_std = noise_std; p.noise_clip = noise_clip;
       p.C2 = out2; p.ldc2 = (int)ld_out2;
     }
-    if (l == L - 1 && skinny_ok(d->dims[l + 1], p.K)) {  // out features <= 16: streaming VALU kernel, no MFMA tile waste
+    if (l == L - 1 && skinny_fwd_ok(d->dims[l + 1], p.K)) {  // out features <= 16: streaming VALU kernel, no MFMA tile waste
       SkinnyP q = {};
       q.X = p.A; q.ldx = p.lda; q.sX = p.sA;
       q.W = p.B; q.ldk = p.ldb; q.sW = p.sB;
@@ -555,7 +555,7 @@ extern "C" int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const
       pqlk_mlp_act_offset(d, b, 0, l - 1, &i_off, &in_ld);
       in = acts + i_off; in_stride = b * in_ld;
     }
-    const bool skinny = (l == L - 1) && skinny_ok(d->dims[l + 1], (int)ld_in) && in_ld >= ld_in;
+    const bool skinny = (l == L - 1) && skinny_bwd_ok(d->dims[l + 1], (int)ld_in) && in_ld >= ld_in;
     if (skinny) {
       SkinnyP q = {};
       q.X = in; q.ldx = (int)in_ld; q.sX = in_stride;

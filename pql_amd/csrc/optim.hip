@@ -171,18 +171,26 @@ __global__ __launch_bounds__(256) void k_moments_stage1(const float* __restrict_
   }
 }
 
+// block = 4 columns x 64 chunks: every partial is fetched by its own thread (one round trip), then one thread per
+// column folds the 64 chunk moments from LDS in fixed order.
 __global__ __launch_bounds__(256) void k_moments_stage2(const float* __restrict__ part, int chunks, int cols, int64_t n,
                                                         float* __restrict__ mean_out, float* __restrict__ var_out) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= cols) return;
+  __shared__ float sh[4][MOM_CHUNKS][3];
+  const int cc = threadIdx.x >> 6, ch = threadIdx.x & 63;
+  const int col = blockIdx.x * 4 + cc;
+  if (col < cols && ch < chunks) {
+    const float* o = part + ((int64_t)ch * cols + col) * 3;
+    sh[cc][ch][0] = o[0]; sh[cc][ch][1] = o[1]; sh[cc][ch][2] = o[2];
+  }
+  __syncthreads();
+  if (ch != 0 || col >= cols) return;
   float cnt = 0.f, mean = 0.f, m2 = 0.f;
   for (int c = 0; c < chunks; ++c) {
-    const float* o = part + ((int64_t)c * cols + col) * 3;
-    const float nb = o[0];
+    const float nb = sh[cc][c][0];
     if (nb <= 0.f) continue;
-    const float delta = o[1] - mean, tot = cnt + nb;
+    const float delta = sh[cc][c][1] - mean, tot = cnt + nb;
     mean += delta * nb / tot;
-    m2 += o[2] + delta * delta * cnt * nb / tot;
+    m2 += sh[cc][c][2] + delta * delta * cnt * nb / tot;
     cnt = tot;
   }
   mean_out[col] = mean;
@@ -199,7 +207,7 @@ extern "C" int pqlk_batch_moments(const float* x, int64_t ldx, int64_t n, int32_
   hipLaunchKernelGGL(k_moments_stage1, dim3((cols + 31) / 32, chunks), dim3(256), 0, pqlk_s(stream), x, ldx, n, (int)cols,
                      rows_per_chunk, scratch);
   PQLK_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_moments_stage2, dim3((cols + 255) / 256), dim3(256), 0, pqlk_s(stream), scratch, chunks, (int)cols, n,
+  hipLaunchKernelGGL(k_moments_stage2, dim3((cols + 3) / 4), dim3(256), 0, pqlk_s(stream), scratch, chunks, (int)cols, n,
                      mean_out, var_out);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;

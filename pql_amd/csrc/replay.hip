@@ -128,7 +128,21 @@ __device__ __forceinline__ float norm1(float x, float mean, float sd, int clamp5
 
 #define GATHER_MAX_OBS 1024
 
-template <bool HAS_NORM>
+// store up to 4 consecutive columns [col, col+4) of a row, clipped to `limit` columns; one 16-B store when the
+// destination is 16-B aligned and unclipped, scalar stores otherwise
+__device__ __forceinline__ void store4(float* __restrict__ row, int col, int limit, const float e[4], bool aligned) {
+  if (aligned && col + 4 <= limit) {
+    *reinterpret_cast<float4*>(row + col) = make_float4(e[0], e[1], e[2], e[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (col + j < limit) row[col + j] = e[j];
+  }
+}
+
+// R rows per wave per trip with all their record loads in flight at once (memory-level parallelism for the random
+// HBM reads); CH = 16-B chunks per lane per record (1 covers records up to 1 KiB, e.g. cfg #2's 784 used bytes).
+template <bool HAS_NORM, int R, int CH>
 __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __restrict__ records, RecLayout L,
                                                              int64_t capacity, const int64_t* __restrict__ idx, int64_t b,
                                                              const float* __restrict__ mean, const float* __restrict__ var,
@@ -153,73 +167,87 @@ __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __rest
   const int nchunk = L.used >> 2;
   const int A = L.A < 0 ? 0 : L.A;
   const int sa_cols = L.O + A;
-  for (int64_t r = wave; r < b; r += nwaves) {
-    int64_t src = idx[r];
-    if (src < 0 || src >= capacity) src = 0;
-    const float4* rec4 = reinterpret_cast<const float4*>(records + src * L.ld);
-    float* xs = x_sa ? x_sa + r * ld_sa : nullptr;
-    float* xns = xn_sa ? xn_sa + r * ld_sa : nullptr;
-    float* xno = xn_obs ? xn_obs + r * ld_o : nullptr;
-    for (int q = lane; q < nchunk; q += 64) {
-      float4 v = rec4[q];
-      float e[4] = {v.x, v.y, v.z, v.w};
-      const int c = q << 2;
-      if (c < L.o4) {  // obs
-        if (HAS_NORM) {
+  const bool act_aligned = (L.O & 3) == 0;
+  for (int64_t r0 = wave * R; r0 < b; r0 += nwaves * R) {
+    float4 v[R][CH];
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (c + j < L.O) e[j] = norm1(e[j], s_mean[c + j], s_sd[c + j], clamp5);
-        }
-        if (L.A < 0) {  // obs-only ring: the sample IS the learner's obs batch
+    for (int i = 0; i < R; ++i) {
+      const int64_t r = r0 + i;
+      int64_t src = r < b ? idx[r] : 0;
+      if (src < 0 || src >= capacity) src = 0;  // never fault on a bad index
+      const float4* rec4 = reinterpret_cast<const float4*>(records + src * L.ld);
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (c + j < L.O) {
-              if (xs) xs[c + j] = e[j];
-              if (xno) xno[c + j] = e[j];
-            }
-        } else if (xs) {
+      for (int c = 0; c < CH; ++c) {
+        const int q = lane + 64 * c;
+        v[i][c] = q < nchunk ? rec4[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (c + j < L.O) xs[c + j] = e[j];
-        }
-      } else if (L.A >= 0) {
-        if (c < L.off_act) {  // next_obs
-          const int cc = c - L.off_nobs;
+    for (int i = 0; i < R; ++i) {
+      const int64_t r = r0 + i;
+      if (r >= b) break;
+      float* xs = x_sa ? x_sa + r * ld_sa : nullptr;
+      float* xns = xn_sa ? xn_sa + r * ld_sa : nullptr;
+      float* xno = xn_obs ? xn_obs + r * ld_o : nullptr;
+#pragma unroll
+      for (int cch = 0; cch < CH; ++cch) {
+        const int q = lane + 64 * cch;
+        if (q >= nchunk) continue;
+        float e[4] = {v[i][cch].x, v[i][cch].y, v[i][cch].z, v[i][cch].w};
+        const int c = q << 2;
+        if (c < L.o4) {  // obs
           if (HAS_NORM) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              if (cc + j < L.O) e[j] = norm1(e[j], s_mean[cc + j], s_sd[cc + j], clamp5);
+              if (c + j < L.O) e[j] = norm1(e[j], s_mean[c + j], s_sd[c + j], clamp5);
           }
+          if (xs) store4(xs, c, L.O, e, true);
+          if (L.A < 0 && xno) store4(xno, c, L.O, e, true);  // obs-only ring: the sample IS the learner's obs batch
+        } else if (L.A >= 0) {
+          if (c < L.off_act) {  // next_obs
+            const int cc = c - L.off_nobs;
+            if (HAS_NORM) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (cc + j < L.O) {
-              if (xns) xns[cc + j] = e[j];
-              if (xno) xno[cc + j] = e[j];
+              for (int j = 0; j < 4; ++j)
+                if (cc + j < L.O) e[j] = norm1(e[j], s_mean[cc + j], s_sd[cc + j], clamp5);
             }
-        } else if (c < L.off_rd) {  // action -> columns O.. of the critic input
-          const int cc = c - L.off_act;
-          if (xs) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              if (cc + j < L.A) xs[L.O + cc + j] = e[j];
+            if (xns) store4(xns, cc, L.O, e, true);
+            if (xno) store4(xno, cc, L.O, e, true);
+          } else if (c < L.off_rd) {  // action -> columns O.. of the critic input
+            const int cc = c - L.off_act;
+            if (xs) store4(xs + L.O, cc, L.A, e, act_aligned);
+          } else {
+            if (o_rew) o_rew[r] = e[0];
+            if (o_done) o_done[r] = e[1];
           }
-        } else {
-          if (o_rew) o_rew[r] = e[0];
-          if (o_done) o_done[r] = e[1];
         }
       }
+      // zero the pad columns so the GEMM K-loop can run over the padded width unchecked
+      for (int c = sa_cols + lane; c < ld_sa; c += 64) {
+        if (xs) xs[c] = 0.f;
+        if (xns) xns[c] = 0.f;
+      }
+      if (L.A < 0 && xs) {
+        for (int c = L.O + lane; c < sa_cols; c += 64) xs[c] = 0.f;
+      }
+      if (xno)
+        for (int c = L.O + lane; c < ld_o; c += 64) xno[c] = 0.f;
     }
-    // zero the pad columns so the GEMM K-loop can run over the padded width unchecked
-    for (int c = sa_cols + lane; c < ld_sa; c += 64) {
-      if (xs) xs[c] = 0.f;
-      if (xns) xns[c] = 0.f;
-    }
-    if (L.A < 0 && xs) {
-      for (int c = L.O + lane; c < sa_cols; c += 64) xs[c] = 0.f;
-    }
-    if (xno)
-      for (int c = L.O + lane; c < ld_o; c += 64) xno[c] = 0.f;
   }
+}
+
+template <bool HAS_NORM>
+static void launch_gather_fused(int nchunk, unsigned blocks, hipStream_t st, const float* records, RecLayout L, int64_t capacity,
+                                const int64_t* idx, int64_t b, const float* mean, const float* var, float eps, int clamp5,
+                                float* x_sa, int64_t ld_sa, float* xn_sa, float* xn_obs, int64_t ld_o, float* rew, float* done) {
+#define PQLK_GF(R, CH)                                                                                                   \
+  hipLaunchKernelGGL((k_replay_gather_fused<HAS_NORM, R, CH>), dim3(blocks), dim3(256), 0, st, records, L, capacity, idx, b, \
+                     mean, var, eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done)
+  if (nchunk <= 64) PQLK_GF(4, 1);
+  else if (nchunk <= 128) PQLK_GF(2, 2);
+  else if (nchunk <= 256) PQLK_GF(1, 4);
+  else PQLK_GF(1, 16);
+#undef PQLK_GF
 }
 
 extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t* idx, int64_t b, const float* mean,
@@ -236,15 +264,17 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
   if (xn_obs) PQLK_REQUIRE(ld_o % 32 == 0 && ld_o >= L.O, PQLK_E_ALIGN);
   if (L.A < 0) PQLK_REQUIRE(xn_sa == nullptr, PQLK_E_UNSUPPORTED);
   if (b == 0) return PQLK_OK;
-  int64_t blocks = (b + 3) / 4;
-  if (blocks > 8192) blocks = 8192;
+  PQLK_REQUIRE((L.used >> 2) <= 1024, PQLK_E_UNSUPPORTED);
+  const int nchunk = L.used >> 2;
+  const int rows_per_wave = nchunk <= 64 ? 4 : (nchunk <= 128 ? 2 : 1);
+  int64_t blocks = (b + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
+  if (blocks > 2048) blocks = 2048;
   if (mean)
-    hipLaunchKernelGGL(k_replay_gather_fused<true>, dim3((unsigned)blocks), dim3(256), 0, pqlk_s(stream), ring->records,
-                       L, ring->capacity, idx, b, mean, var, eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done);
+    launch_gather_fused<true>(nchunk, (unsigned)blocks, pqlk_s(stream), ring->records, L, ring->capacity, idx, b, mean, var, eps,
+                              clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done);
   else
-    hipLaunchKernelGGL(k_replay_gather_fused<false>, dim3((unsigned)blocks), dim3(256), 0, pqlk_s(stream),
-                       ring->records, L, ring->capacity, idx, b, mean, var, eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o,
-                       rew, done);
+    launch_gather_fused<false>(nchunk, (unsigned)blocks, pqlk_s(stream), ring->records, L, ring->capacity, idx, b, mean, var, eps,
+                               clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }

@@ -131,56 +131,87 @@ __global__ __launch_bounds__(256) void k_skinny_dx(SkinnyP p) {
 }
 
 // ---------------------------------------------------------------------------------------------- dW, db (split-batch slabs)
-// grid = (ceil(K/64), splits, groups); block = 64 columns x 4 row-lanes.
+// grid = (ceil(K/64), splits, groups); block = 16 column-lanes (float4 = 64 columns) x 16 row-lanes.  Each thread
+// streams its rows with 4 independent 16-B loads in flight; the 16 row-lanes are folded through LDS in fixed order.
+#define SKDW_ROWS 128
 __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
-  __shared__ float dy_lds[128][SKINNY_MAX_N + 1];
-  __shared__ float red[4][64][SKINNY_MAX_N + 1];
+  __shared__ float dy_lds[SKDW_ROWS][SKINNY_MAX_N + 1];
+  __shared__ __attribute__((aligned(16))) float red[16][16][4];
+  __shared__ float redb[16][SKINNY_MAX_N];
   const int g = blockIdx.z, split = blockIdx.y;
-  const int cx = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cx;
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int col = blockIdx.x * 64 + 4 * cl;
   const float* X = p.X + (long long)g * p.sX;
   const float* dY = p.dY + (long long)g * p.sY;
   const int m_beg = split * p.rows_per_split;
   const int m_end = min(p.M, m_beg + p.rows_per_split);
-  float acc[SKINNY_MAX_N];
+  float4 acc[SKINNY_MAX_N];
 #pragma unroll
-  for (int n = 0; n < SKINNY_MAX_N; ++n) acc[n] = 0.f;
+  for (int n = 0; n < SKINNY_MAX_N; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
   float dbacc = 0.f;
-  for (int m0 = m_beg; m0 < m_end; m0 += 128) {
+  const bool col_ok = col < p.K;
+  for (int m0 = m_beg; m0 < m_end; m0 += SKDW_ROWS) {
     __syncthreads();
-    for (int i = threadIdx.x; i < 128 * p.N; i += 256) {
+    for (int i = threadIdx.x; i < SKDW_ROWS * p.N; i += 256) {
       const int r = i / p.N, n = i % p.N;
       dy_lds[r][n] = (m0 + r < m_end) ? dY[(long long)(m0 + r) * p.ldy + n] : 0.f;
     }
     __syncthreads();
-    const int rows = min(128, m_end - m0);
-    for (int r = rl; r < rows; r += 4) {
-      const float hv = col < p.K ? X[(long long)(m0 + r) * p.ldx + col] : 0.f;
+    // rows rl, rl+16, ... of this 128-row chunk: 8 rows per thread, loads issued 4 at a time
 #pragma unroll
-      for (int n = 0; n < SKINNY_MAX_N; ++n)
-        if (n < p.N) acc[n] += dy_lds[r][n] * hv;
-      if (blockIdx.x == 0 && cx < p.N) dbacc += dy_lds[r][cx];
+    for (int u = 0; u < SKDW_ROWS / 16; u += 4) {
+      float4 hv[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = rl + 16 * (u + v);
+        hv[v] = (col_ok && m0 + r < m_end) ? *reinterpret_cast<const float4*>(X + (long long)(m0 + r) * p.ldx + col)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = rl + 16 * (u + v);
+#pragma unroll
+        for (int n = 0; n < SKINNY_MAX_N; ++n) {
+          if (n < p.N) {
+            const float d = dy_lds[r][n];
+            acc[n].x += d * hv[v].x; acc[n].y += d * hv[v].y; acc[n].z += d * hv[v].z; acc[n].w += d * hv[v].w;
+          }
+        }
+        if (blockIdx.x == 0 && cl < p.N) dbacc += dy_lds[r][cl];
+      }
     }
   }
-#pragma unroll
-  for (int n = 0; n < SKINNY_MAX_N; ++n) red[rl][cx][n] = acc[n];
-  red[rl][cx][SKINNY_MAX_N] = dbacc;
-  __syncthreads();
-  if (rl == 0) {
-    float* dW = p.dW + (long long)g * p.sW + (long long)split * p.sSplit;
-    if (col < p.K) {
-      for (int n = 0; n < p.N; ++n)
-        dW[(long long)n * p.ldk + col] = ((red[0][cx][n] + red[1][cx][n]) + red[2][cx][n]) + red[3][cx][n];
+  float* dW = p.dW + (long long)g * p.sW + (long long)split * p.sSplit;
+  for (int n = 0; n < p.N; ++n) {
+    __syncthreads();
+    *reinterpret_cast<float4*>(&red[rl][cl][0]) = acc[n];
+    __syncthreads();
+    if (rl == 0 && col_ok) {
+      float4 s = *reinterpret_cast<float4*>(&red[0][cl][0]);
+      for (int k = 1; k < 16; ++k) {
+        const float4 t = *reinterpret_cast<float4*>(&red[k][cl][0]);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+      *reinterpret_cast<float4*>(dW + (long long)n * p.ldk + col) = s;
     }
-    if (blockIdx.x == 0 && cx < p.ldc) {  // ldc = pqlk_ld(N): zero the bias pad
+  }
+  if (blockIdx.x == 0) {
+    if (cl < SKINNY_MAX_N) redb[rl][cl] = dbacc;
+    __syncthreads();
+    if (threadIdx.x < p.ldc) {  // ldc = pqlk_ld(N) <= 32: zero the bias pad
       float* dB = p.dB + (long long)g * p.sBias + (long long)split * p.sSplit;
-      const int S = SKINNY_MAX_N;
-      dB[cx] = cx < p.N ? ((red[0][cx][S] + red[1][cx][S]) + red[2][cx][S]) + red[3][cx][S] : 0.f;
+      float s = 0.f;
+      if ((int)threadIdx.x < p.N)
+        for (int k = 0; k < 16; ++k) s += redb[k][threadIdx.x];
+      dB[threadIdx.x] = s;
     }
   }
 }
 
-static inline bool skinny_ok(int n_out, int k_padded) { return n_out <= SKINNY_MAX_N && k_padded <= SKINNY_MAX_K; }
+// forward: one wave_sum per output, so only worth it for a handful of outputs (the Q head); backward variants
+// stream and stay ahead of a 64x64 MFMA tile up to 16 outputs.
+static inline bool skinny_fwd_ok(int n_out, int k_padded) { return n_out <= 4 && k_padded <= SKINNY_MAX_K; }
+static inline bool skinny_bwd_ok(int n_out, int k_padded) { return n_out <= SKINNY_MAX_N && k_padded <= SKINNY_MAX_K; }
 
 static int launch_skinny_fwd(const SkinnyP& p, int groups, hipStream_t st) {
   int blocks = (p.M + 3) / 4;
