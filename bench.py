@@ -127,24 +127,28 @@ class Schedule:
         self.r_p = int(cfg.algo.critic_actor_ratio)
         self.r_env = int(cfg.algo.critic_sample_ratio)
         self.global_steps = 0
+        self.pending = None
 
     def step(self):
+        """Rollout is software-pipelined one slice ahead, like the reference's asynchronous actor: the transitions
+        handed to the learners at slice i were produced (on the rollout queue) while the learners ran slice i-1."""
         k = self.k
         self.k += 1
         if not self.v_only and k % self.r_env == 0:
             sim = torch.cuda.current_stream(self.device)          # rollout queue
+            if self.pending is not None:
+                p_data, v_data, rms = self.pending
+                self.p.critic_stream = self.v.stream
+                self.v.update(self.actor.actor, v_data, rms, 0)  # transitions + policy replica -> V-learner (its queue)
+                self.p.update(self.v.critic, p_data, rms, 0)     # obs + critic replica -> P-learner (its queue)
             if self.p.stream is not None:
                 sim.wait_stream(self.p.stream)                    # newest policy weights come from the P-learner's queue
+                sim.wait_stream(self.v.stream)                    # and the learners are done reading the last hand-off
             self.actor.actor.arena.data.copy_(self.p.actor.arena.data)
             p_data, v_data, n = self.actor.explore_env(self.env, self.cfg.algo.horizon_len, random=False)
             self.global_steps += n
-            rms = self.actor.obs_rms.get_states(self.device)
-            self.p.critic_stream = self.v.stream
-            self.v.update(self.actor.actor, v_data, rms, 0)      # transitions + policy replica -> V-learner (its queue)
-            self.p.update(self.v.critic, p_data, rms, 0)         # obs + critic replica -> P-learner (its queue)
-            if self.v.stream is not None:                         # the rollout may not recycle these buffers early
-                sim.wait_stream(self.v.stream)
-                sim.wait_stream(self.p.stream)
+            rms = tuple(t.clone() if torch.is_tensor(t) else t for t in self.actor.obs_rms.get_states(self.device))
+            self.pending = (p_data, v_data, rms)
         self.v.learn()
         if not self.v_only and k % self.r_p == self.r_p - 1:
             self.p.learn()
