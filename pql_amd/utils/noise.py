@@ -7,6 +7,9 @@ def _draw(shape, dtype, device, std):
     return torch.empty(shape, dtype=dtype, device=device).normal_() * std
 
 
+_STD_CACHE = {}
+
+
 def add_normal_noise(x, std, noise_bounds=None, out_bounds=None):
     noise = _draw(x.shape, x.dtype, x.device, std)
     if noise_bounds is not None:
@@ -19,7 +22,11 @@ def add_mixed_normal_noise(x, std_max, std_min, noise_bounds=None, out_bounds=No
     """Per-env sigma = linspace(std_min, std_max, N)[env].  env_offset/total_envs let a data-parallel
     rank index the GLOBAL env axis."""
     n = x.shape[0] if total_envs is None else total_envs
-    std = torch.linspace(std_min, std_max, n)[env_offset: env_offset + x.shape[0]].to(x.device).unsqueeze(-1)
+    key = (float(std_min), float(std_max), int(n), int(env_offset), int(x.shape[0]), str(x.device))
+    std = _STD_CACHE.get(key)
+    if std is None:   # built on the host like the reference (same fp32 values), uploaded ONCE: no per-step H2D sync
+        std = torch.linspace(std_min, std_max, n)[env_offset: env_offset + x.shape[0]].to(x.device).unsqueeze(-1)
+        _STD_CACHE[key] = std
     noise = _draw(x.shape, x.dtype, x.device, 1.0) * std
     if noise_bounds is not None:
         noise = noise.clamp(noise_bounds[0], noise_bounds[1])
