@@ -116,7 +116,7 @@ struct Smem {
 // magnitude inside the 1e-5 parity bar, and ~6 us cheaper per 8192x512x2 epilogue than libm's expm1f.
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
-template <int MODE, int BM, int BN>
+template <int MODE, int BM, int BN, int EPI>
 __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
   constexpr int WM = BM / 2, WN = BN / 2;  // per-wave patch
   constexpr int MI = WM / 32, NJ = WN / 32;
@@ -290,10 +290,14 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
     return;
   }
 
+  // EPI is a compile-time parameter: one straight-line epilogue per instantiation (a runtime switch inside the
+  // 64-element unrolled store loop inlined tanhf/expf four times over and cost ~10 us per launch).
   const int g = (MODE == MODE_DX && p.zsum) ? 0 : g0;
   float* C = p.C + (long long)g * p.sC;
   const float* bias = (MODE == MODE_FWD && p.bias) ? p.bias + (long long)g * p.sBias : nullptr;
   const float* aux = p.aux ? p.aux + (long long)g * p.sAux : nullptr;
+  // full = the whole 128/64-wide tile lies inside the matrix: no per-element bounds tests
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && EPI != EPI_DTANH_SLICE;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -303,78 +307,91 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (row >= p.M) continue;
         float v = acc[i][j][e];
-        if (MODE == MODE_FWD) {
-          if (col >= p.ncols_store) continue;
-          if (col < p.N) {
+        if (EPI == EPI_DTANH_SLICE) {
+          const int cc = col - p.col0;
+          if (row < p.M && cc >= 0 && cc < p.ncol) {
+            const float a = aux[(long long)row * p.ldaux + cc];
+            C[(long long)row * p.ldc + cc] = v * (1.f - a * a);
+          }
+          continue;
+        }
+        const bool in_rows = full || row < p.M;
+        const bool in_cols = full || col < p.N;
+        if (!in_rows || (!in_cols && col >= p.ncols_store)) continue;
+        if (in_cols) {
+          if (MODE == MODE_FWD) {
             v += bv;
-            if (p.epi == EPI_ELU) v = elu1(v);
-            else if (p.epi == EPI_TANH) v = tanhf(v);
-            else if (p.epi == EPI_TANH_NOISE) {
+            if (EPI == EPI_ELU) v = elu1(v);
+            else if (EPI == EPI_TANH) v = tanhf(v);
+            else if (EPI == EPI_TANH_NOISE) {
               v = tanhf(v);
               float nz = p.noise_std * aux[(long long)row * p.N + col];
               nz = fminf(fmaxf(nz, -p.noise_clip), p.noise_clip);
               v = fminf(fmaxf(v + nz, -1.f), 1.f);
             }
-          } else {
-            v = 0.f;
+          } else if (EPI == EPI_DELU) {
+            const float hval = aux[(long long)row * p.ldaux + col];
+            v = hval > 0.f ? v : v * (hval + 1.f);  // ELU'(x) = exp(x) = elu(x) + 1 for x <= 0
           }
-          C[(long long)row * p.ldc + col] = v;
-          if (p.C2 && g == 0 && col < p.N) p.C2[(long long)row * p.ldc2 + col] = v;
-        } else {  // MODE_DX
-          if (p.epi == EPI_DTANH_SLICE) {
-            const int cc = col - p.col0;
-            if (cc < 0 || cc >= p.ncol) continue;
-            const float a = aux[(long long)row * p.ldaux + cc];
-            C[(long long)row * p.ldc + cc] = v * (1.f - a * a);
-          } else {
-            if (col >= p.ncols_store) continue;
-            if (col < p.N) {
-              if (p.epi == EPI_DELU) {
-                const float hval = aux[(long long)row * p.ldaux + col];
-                v = hval > 0.f ? v : v * (hval + 1.f);  // ELU'(x) = exp(x) = elu(x) + 1 for x <= 0
-              }
-            } else {
-              v = 0.f;
-            }
-            C[(long long)row * p.ldc + col] = v;
-          }
+        } else {
+          v = 0.f;  // pad column
         }
+        C[(long long)row * p.ldc + col] = v;
+        if (MODE == MODE_FWD && p.C2 && g == 0 && in_cols) p.C2[(long long)row * p.ldc2 + col] = v;
       }
     }
 }
 
-template <int MODE, int BM, int BN>
+template <int MODE, int BM, int BN, int EPI>
 static int launch_gemm(GemmP p, int gz, hipStream_t st) {
   using S = Smem<MODE, BM, BN>;
   const size_t shmem = (size_t)2 * S::STAGE * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, BM, BN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, BM, BN, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return -(int)e;
     attr_set = true;
   }
   int ncols = (MODE == MODE_DW) ? p.N : p.ncols_store;
   p.n_base = 0;
-  if (MODE == MODE_DX && p.epi == EPI_DTANH_SLICE) {  // only the action columns are wanted
+  if (MODE == MODE_DX && EPI == EPI_DTANH_SLICE) {  // only the action columns are wanted
     p.n_base = p.col0 & ~3;
     ncols = p.col0 + p.ncol - p.n_base;
   }
   dim3 grid((unsigned)((ncols + BN - 1) / BN), (unsigned)((p.M + BM - 1) / BM), (unsigned)gz);
-  hipLaunchKernelGGL((k_gemm<MODE, BM, BN>), grid, dim3(256), shmem, st, p);
+  hipLaunchKernelGGL((k_gemm<MODE, BM, BN, EPI>), grid, dim3(256), shmem, st, p);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }
 
 // Pick the tile: 128x128 when that already gives every CU a block, else 64x64.
-template <int MODE>
-static int launch_auto(const GemmP& p, int gz, hipStream_t st) {
+template <int MODE, int EPI>
+static int launch_tile(const GemmP& p, int gz, hipStream_t st) {
   const int ncols = (MODE == MODE_DW) ? p.N : p.ncols_store;
   const long long big = (long long)((p.M + 127) / 128) * ((ncols + 127) / 128) * gz;
-  if (big >= 256 && ncols >= 128) return launch_gemm<MODE, 128, 128>(p, gz, st);
-  return launch_gemm<MODE, 64, 64>(p, gz, st);
+  if (big >= 256 && ncols >= 128 && EPI != EPI_DTANH_SLICE) return launch_gemm<MODE, 128, 128, EPI>(p, gz, st);
+  return launch_gemm<MODE, 64, 64, EPI>(p, gz, st);
+}
+
+template <int MODE>
+static int launch_auto(const GemmP& p, int gz, hipStream_t st) {
+  if (MODE == MODE_FWD) {
+    switch (p.epi) {
+      case EPI_ELU: return launch_tile<MODE_FWD, EPI_ELU>(p, gz, st);
+      case EPI_TANH: return launch_tile<MODE_FWD, EPI_TANH>(p, gz, st);
+      case EPI_TANH_NOISE: return launch_tile<MODE_FWD, EPI_TANH_NOISE>(p, gz, st);
+      default: return launch_tile<MODE_FWD, EPI_NONE>(p, gz, st);
+    }
+  } else if (MODE == MODE_DX) {
+    switch (p.epi) {
+      case EPI_DELU: return launch_tile<MODE_DX, EPI_DELU>(p, gz, st);
+      case EPI_DTANH_SLICE: return launch_tile<MODE_DX, EPI_DTANH_SLICE>(p, gz, st);
+      default: return launch_tile<MODE_DX, EPI_NONE>(p, gz, st);
+    }
+  }
+  return launch_tile<MODE_DW, EPI_NONE>(p, gz, st);
 }
 
 // ================================================================================================
