@@ -11,6 +11,8 @@
 //
 // MFMA operand maps (cdna_hip_programming.md section 3): lane l = (r = l&31, h = l>>5):
 //   A operand = A[i=r][k=h], B operand = B[k=h][j=r]; D: col = r, row = (reg&3) + 8*(reg>>2) + 4*h.
+// The kernels feed the WEIGHT-side fragment as the MFMA's A operand and the batch-side fragment as B, i.e. they
+// compute the transposed tile, so that a lane owns one output row and four consecutive columns per register quad.
 // A 32-wide reduction step is consumed as 4 groups (k8) x 4 MFMAs (t); lane half h supplies reduction
 // index kk = 8*k8 + 4*h + t.  A and B use the same map, so any such bijection is a valid dot product;
 // this one lets k-contiguous operands be fetched with one ds_read_b128 per four MFMAs.
@@ -45,22 +47,27 @@ struct GemmP {
   float noise_std, noise_clip;
 };
 
-#define KT 32       // reduction elements per LDS stage
-#define KC_LD 36    // row stride of a k-contiguous tile (32 + 4: odd multiple of 4 -> conflict-free b128 reads)
+#define KT_MAX 32   // reduction elements per LDS stage (template parameter KT: 32 or 16)
+#ifndef PQLK_KT
+#define PQLK_KT 32
+#endif
+// row stride of a k-contiguous tile = KT + 4 floats (36 or 20: odd multiple of 4 -> conflict-free b128 reads)
 
 // ---- tile loaders: global -> registers -> LDS -------------------------------------------------
 // k-contiguous tile: ROWS rows x 32 floats.  Chunk c (16 B): row = c>>3, kc = c&7.
-template <int ROWS>
+template <int ROWS, int KT>
 struct KcTile {
-  static constexpr int CH = ROWS * 8 / 256;  // float4 chunks per thread
+  static constexpr int CPR = KT / 4;            // 16-B chunks per row
+  static constexpr int LD = KT + 4;
+  static constexpr int CH = ROWS * CPR / 256;   // float4 chunks per thread
   float4 v[CH];
   __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int row_lim, int k0, int k_lim,
                                        int tid) {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = tid + 256 * i;
-      const int row = row0 + (c >> 3);
-      const int k = k0 + ((c & 7) << 2);
+      const int row = row0 + c / CPR;
+      const int k = k0 + ((c % CPR) << 2);
       if (row < row_lim && k < k_lim)
         v[i] = *reinterpret_cast<const float4*>(base + (long long)row * ld + k);
       else
@@ -71,16 +78,16 @@ struct KcTile {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = tid + 256 * i;
-      *reinterpret_cast<float4*>(lds + (c >> 3) * KC_LD + ((c & 7) << 2)) = v[i];
+      *reinterpret_cast<float4*>(lds + (c / CPR) * LD + ((c % CPR) << 2)) = v[i];
     }
   }
 };
 
-// reduction-row tile: 32 rows x COLS floats, row stride COLS+4.  Chunk c: row = c / (COLS/4), cc = c % (COLS/4).
-template <int COLS>
+// reduction-row tile: KT rows x COLS floats, row stride COLS+4.  Chunk c: row = c / (COLS/4), cc = c % (COLS/4).
+template <int COLS, int KT>
 struct RrTile {
   static constexpr int CPR = COLS / 4;
-  static constexpr int CH = 32 * CPR / 256;
+  static constexpr int CH = KT * CPR / 256;
   static constexpr int LD = COLS + 4;
   float4 v[CH];
   __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int row_lim, int col0, int col_lim,
@@ -105,10 +112,10 @@ struct RrTile {
   }
 };
 
-template <int MODE, int BM, int BN>
+template <int MODE, int BM, int BN, int KT>
 struct Smem {
-  static constexpr int A_FLOATS = (MODE == MODE_DW) ? 32 * (BM + 4) : BM * KC_LD;
-  static constexpr int B_FLOATS = (MODE == MODE_FWD) ? BN * KC_LD : 32 * (BN + 4);
+  static constexpr int A_FLOATS = (MODE == MODE_DW) ? KT * (BM + 4) : BM * (KT + 4);
+  static constexpr int B_FLOATS = (MODE == MODE_FWD) ? BN * (KT + 4) : KT * (BN + 4);
   static constexpr int STAGE = A_FLOATS + B_FLOATS;
 };
 
@@ -116,11 +123,12 @@ struct Smem {
 // magnitude inside the 1e-5 parity bar, and ~6 us cheaper per 8192x512x2 epilogue than libm's expm1f.
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
-template <int MODE, int BM, int BN, int EPI>
+template <int MODE, int BM, int BN, int EPI, int KT>
 __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
   constexpr int WM = BM / 2, WN = BN / 2;  // per-wave patch
   constexpr int MI = WM / 32, NJ = WN / 32;
-  using S = Smem<MODE, BM, BN>;
+  constexpr int KC_LD = KT + 4;
+  using S = Smem<MODE, BM, BN, KT>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
@@ -165,10 +173,10 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
     if (nk <= 0) continue;
 
     // register prefetch buffers
-    KcTile<BM> a_kc;
-    RrTile<BM> a_rr;
-    KcTile<BN> b_kc;
-    RrTile<BN> b_rr;
+    KcTile<BM, KT> a_kc;
+    RrTile<BM, KT> a_rr;
+    KcTile<BN, KT> b_kc;
+    RrTile<BN, KT> b_rr;
 
     auto gload = [&](int kt) {
       const int k0 = kbeg + kt * KT;
@@ -215,11 +223,11 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
 
       if (MODE == MODE_DW && blockIdx.x == 0 && tid < BM) {
 #pragma unroll 8
-        for (int rr = 0; rr < 32; ++rr) dbacc += sa[rr * (BM + 4) + tid];
+        for (int rr = 0; rr < KT; ++rr) dbacc += sa[rr * (BM + 4) + tid];
       }
 
 #pragma unroll
-      for (int k8 = 0; k8 < 4; ++k8) {
+      for (int k8 = 0; k8 < KT / 8; ++k8) {
         float af[MI][4], bf[NJ][4];
 #if defined(PQLK_PROBE_NOLDS)   // tuning probe only: operands from registers, pure MFMA issue rate
 #pragma unroll
@@ -258,7 +266,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
           for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][t], af[i][t], acc[i][j], 0, 0, 0);
       }
 
 #if !defined(PQLK_PROBE_NOLOAD)
@@ -269,17 +277,22 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
   }
 
   // ------------------------------------------------------------------------------ epilogue
+  // Accumulator layout after the operand swap (the MFMA computes the TRANSPOSED 32x32 tile): lane (r, h) owns output
+  // row `.. + r` and, in register quad q = e>>2, the four consecutive columns `.. + 8q + 4h + (e&3)`: every quad is one
+  // 16-B store / load instead of four scalar ones (the epilogue is store-issue bound: 64 -> 16 instructions per tile).
   if (MODE == MODE_DW) {
     float* C = p.C + (long long)g0 * p.sC + (long long)split * p.sSplit;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int col = n0 + wn + 32 * j + r;
+        const int row = m0 + wm + 32 * i + r;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (row < p.M && col < p.N) C[(long long)row * p.ldc + col] = acc[i][j][e];
+        for (int q = 0; q < 4; ++q) {
+          const int col = n0 + wn + 32 * j + 8 * q + 4 * h;
+          if (row < p.M && col < p.N)  // N (= padded in-features) is a multiple of 32: a quad is never split
+            *reinterpret_cast<float4*>(C + (long long)row * p.ldc + col) =
+                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
         }
       }
     if (blockIdx.x == 0 && tid < BM && p.dbias) {
@@ -296,60 +309,83 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
   float* C = p.C + (long long)g * p.sC;
   const float* bias = (MODE == MODE_FWD && p.bias) ? p.bias + (long long)g * p.sBias : nullptr;
   const float* aux = p.aux ? p.aux + (long long)g * p.sAux : nullptr;
-  // full = the whole 128/64-wide tile lies inside the matrix: no per-element bounds tests
-  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && EPI != EPI_DTANH_SLICE;
+  // full = the whole tile lies inside the logical matrix: vector path with no per-element bounds tests
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N) && EPI != EPI_DTANH_SLICE && EPI != EPI_TANH_NOISE && !p.C2;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int col = n0 + wn + 32 * j + r;
-      const float bv = (bias && col < p.N) ? bias[col] : 0.f;
+      const int row = m0 + wm + 32 * i + r;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-        float v = acc[i][j][e];
-        if (EPI == EPI_DTANH_SLICE) {
-          const int cc = col - p.col0;
-          if (row < p.M && cc >= 0 && cc < p.ncol) {
-            const float a = aux[(long long)row * p.ldaux + cc];
-            C[(long long)row * p.ldc + cc] = v * (1.f - a * a);
-          }
-          continue;
-        }
-        const bool in_rows = full || row < p.M;
-        const bool in_cols = full || col < p.N;
-        if (!in_rows || (!in_cols && col >= p.ncols_store)) continue;
-        if (in_cols) {
+      for (int q = 0; q < 4; ++q) {
+        const int col = n0 + wn + 32 * j + 8 * q + 4 * h;
+        float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        if (full) {
           if (MODE == MODE_FWD) {
-            v += bv;
-            if (EPI == EPI_ELU) v = elu1(v);
-            else if (EPI == EPI_TANH) v = tanhf(v);
-            else if (EPI == EPI_TANH_NOISE) {
-              v = tanhf(v);
-              float nz = p.noise_std * aux[(long long)row * p.N + col];
-              nz = fminf(fmaxf(nz, -p.noise_clip), p.noise_clip);
-              v = fminf(fmaxf(v + nz, -1.f), 1.f);
+            const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (EPI == EPI_ELU) v[u] = elu1(v[u]);
+              else if (EPI == EPI_TANH) v[u] = tanhf(v[u]);
             }
           } else if (EPI == EPI_DELU) {
-            const float hval = aux[(long long)row * p.ldaux + col];
-            v = hval > 0.f ? v : v * (hval + 1.f);  // ELU'(x) = exp(x) = elu(x) + 1 for x <= 0
+            const float4 h4 = *reinterpret_cast<const float4*>(aux + (long long)row * p.ldaux + col);
+            v[0] = h4.x > 0.f ? v[0] : v[0] * (h4.x + 1.f);  // ELU'(x) = exp(x) = elu(x) + 1 for x <= 0
+            v[1] = h4.y > 0.f ? v[1] : v[1] * (h4.y + 1.f);
+            v[2] = h4.z > 0.f ? v[2] : v[2] * (h4.z + 1.f);
+            v[3] = h4.w > 0.f ? v[3] : v[3] * (h4.w + 1.f);
           }
-        } else {
-          v = 0.f;  // pad column
+          *reinterpret_cast<float4*>(C + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+          continue;
         }
-        C[(long long)row * p.ldc + col] = v;
-        if (MODE == MODE_FWD && p.C2 && g == 0 && in_cols) p.C2[(long long)row * p.ldc2 + col] = v;
+        if (row >= p.M) continue;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // edge tiles, pad columns, slices, second destination: per element
+          const int c = col + u;
+          float x = v[u];
+          if (EPI == EPI_DTANH_SLICE) {
+            const int cc = c - p.col0;
+            if (cc >= 0 && cc < p.ncol) {
+              const float a = aux[(long long)row * p.ldaux + cc];
+              C[(long long)row * p.ldc + cc] = x * (1.f - a * a);
+            }
+            continue;
+          }
+          if (c >= p.ncols_store) continue;
+          if (c < p.N) {
+            if (MODE == MODE_FWD) {
+              x += bias ? bias[c] : 0.f;
+              if (EPI == EPI_ELU) x = elu1(x);
+              else if (EPI == EPI_TANH) x = tanhf(x);
+              else if (EPI == EPI_TANH_NOISE) {
+                x = tanhf(x);
+                float nz = p.noise_std * aux[(long long)row * p.N + c];
+                nz = fminf(fmaxf(nz, -p.noise_clip), p.noise_clip);
+                x = fminf(fmaxf(x + nz, -1.f), 1.f);
+              }
+              if (p.C2 && g == 0) p.C2[(long long)row * p.ldc2 + c] = x;
+            } else if (EPI == EPI_DELU) {
+              const float hval = aux[(long long)row * p.ldaux + c];
+              x = hval > 0.f ? x : x * (hval + 1.f);
+            }
+          } else {
+            x = 0.f;  // pad column
+          }
+          C[(long long)row * p.ldc + c] = x;
+        }
       }
     }
 }
 
 template <int MODE, int BM, int BN, int EPI>
 static int launch_gemm(GemmP p, int gz, hipStream_t st) {
-  using S = Smem<MODE, BM, BN>;
+  constexpr int KT = PQLK_KT;
+  using S = Smem<MODE, BM, BN, KT>;
   const size_t shmem = (size_t)2 * S::STAGE * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, BM, BN, EPI>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, BM, BN, EPI, KT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return -(int)e;
     attr_set = true;
@@ -361,7 +397,7 @@ static int launch_gemm(GemmP p, int gz, hipStream_t st) {
     ncols = p.col0 + p.ncol - p.n_base;
   }
   dim3 grid((unsigned)((ncols + BN - 1) / BN), (unsigned)((p.M + BM - 1) / BM), (unsigned)gz);
-  hipLaunchKernelGGL((k_gemm<MODE, BM, BN, EPI>), grid, dim3(256), shmem, st, p);
+  hipLaunchKernelGGL((k_gemm<MODE, BM, BN, EPI, KT>), grid, dim3(256), shmem, st, p);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }
@@ -580,7 +616,7 @@ extern "C" int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const
       q.M = (int)b; q.N = d->dims[l + 1]; q.K = (int)ld_in; q.ldk = (int)ld_in; q.ldc = (int)ld_out;
       if (grads) {
         q.dW = slabs + w_off; q.dB = slabs + b_off; q.sW = net_stride; q.sBias = net_stride; q.sSplit = arena;
-        q.splits = splits; q.rows_per_split = (int)pqlk_round_up((b + splits - 1) / splits, KT);
+        q.splits = splits; q.rows_per_split = (int)pqlk_round_up((b + splits - 1) / splits, KT_MAX);
         rc = launch_skinny_dw(q, d->n_nets, st);
         if (rc) return rc;
       }
@@ -605,7 +641,7 @@ extern "C" int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const
       p.M = d->dims[l + 1]; p.N = (int)ld_in; p.K = (int)b;
       p.ncols_store = (int)ld_out;
       p.groups = d->n_nets; p.splits = splits;
-      p.rows_per_split = (int)pqlk_round_up((b + splits - 1) / splits, KT);
+      p.rows_per_split = (int)pqlk_round_up((b + splits - 1) / splits, KT_MAX);
       p.sSplit = arena;
       // B operand limit: X has ldx >= ld_in columns; only the first ld_in are wanted.  The loader bounds
       // columns by p.ldb, so clamp through N: tiles never start beyond N and pads inside ldb are zero.

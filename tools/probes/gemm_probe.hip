@@ -80,7 +80,7 @@ int main(int argc, char** argv) {
       p.lda = ldm; p.ldb = ldn; p.ldc = ldn; p.N = ldn; p.ncols_store = ldm;
       p.sA = (long long)B * ldm; p.sB = (long long)B * ldn; p.sC = 512 * 512; p.sBias = 512 * 512;
       p.dbias = Cm + 16 * 2 * 512 * 512;
-      p.splits = s.splits; p.rows_per_split = (int)pqlk_round_up((B + s.splits - 1) / s.splits, KT);
+      p.splits = s.splits; p.rows_per_split = (int)pqlk_round_up((B + s.splits - 1) / s.splits, KT_MAX);
       p.sSplit = 2 * 512 * 512 + 2048;
       gz = s.groups * s.splits;
       flops = 2.0 * s.M * s.N * (double)s.K * s.groups;
@@ -96,5 +96,38 @@ int main(int argc, char** argv) {
     tot_us += us; tot_fl += flops;
   }
   printf("TOTAL %.1f us %.2f GFLOP %.1f TF/s\n", tot_us, tot_fl / 1e9, tot_fl / tot_us / 1e6);
+  {  // two streams
+    hipStream_t sa, sb; hipStreamCreate(&sa); hipStreamCreate(&sb);
+    float* C2b = dalloc((size_t)2 * B * 512, 0.f);
+    auto mk = [&](float* Cout, int K) {
+      GemmP p = {};
+      const int ldk = (int)pqlk_ld(K);
+      p.A = A; p.B = Bm; p.C = Cout; p.bias = bias; p.aux = aux; p.epi = EPI_ELU; p.groups = 2; p.M = B; p.N = 512; p.K = ldk;
+      p.lda = ldk; p.ldb = ldk; p.ldc = 512; p.ncols_store = 512; p.sA = 0; p.sB = (long long)512 * ldk; p.sC = (long long)B * 512; p.sBias = 1024;
+      return p;
+    };
+    for (int K : {128, 512}) {
+      GemmP pa = mk(Cm, K), pb = mk(C2b, K);
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      const int n = 20;
+      for (int rep = 0; rep < 2; ++rep) {
+        hipDeviceSynchronize();
+        hipEventRecord(e0, sa);
+        for (int i = 0; i < 2 * n; ++i) launch_auto<MODE_FWD>(pa, 2, sa);
+        hipEventRecord(e1, sa); hipEventSynchronize(e1);
+        float ms_seq; hipEventElapsedTime(&ms_seq, e0, e1);
+        hipDeviceSynchronize();
+        hipEvent_t fb; hipEventCreate(&fb);
+        hipEventRecord(e0, sa);
+        hipStreamWaitEvent(sb, e0, 0);
+        for (int i = 0; i < n; ++i) { launch_auto<MODE_FWD>(pa, 2, sa); launch_auto<MODE_FWD>(pb, 2, sb); }
+        hipEventRecord(fb, sb); hipStreamWaitEvent(sa, fb, 0);
+        hipEventRecord(e1, sa); hipEventSynchronize(e1);
+        float ms_par; hipEventElapsedTime(&ms_par, e0, e1);
+        if (rep) printf("K=%d fwd x2: %d launches back-to-back %.1f us/launch ; on two streams %.1f us/launch\n", K, 2 * n, ms_seq * 1e3 / (2 * n), ms_par * 1e3 / (2 * n));
+      }
+    }
+  }
   return 0;
 }
+// (appended) two-stream concurrency check: are two independent GEMM chains faster side by side than back to back?
