@@ -336,7 +336,11 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
             v[2] = h4.z > 0.f ? v[2] : v[2] * (h4.z + 1.f);
             v[3] = h4.w > 0.f ? v[3] : v[3] * (h4.w + 1.f);
           }
+#if defined(PQLK_PROBE_NOSTORE)   // tuning probe only: keep the values live, skip the HBM write
+          asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+#else
           *reinterpret_cast<float4*>(C + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+#endif
           continue;
         }
         if (row >= p.M) continue;
