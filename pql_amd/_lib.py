@@ -12,7 +12,7 @@ from pathlib import Path
 import torch
 
 _HERE = Path(__file__).resolve().parent
-LIB_FILE = _HERE / "csrc" / "libpqlk.so"
+LIB_FILE = Path(os.environ.get("PQLK_LIB", _HERE / "csrc" / "libpqlk.so"))   # PQLK_LIB: A/B a tuning build
 
 MAX_LAYERS = 8
 ACT_NONE, ACT_TANH, ACT_TANH_NOISE = 0, 1, 2

@@ -182,17 +182,22 @@ __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
     }
   }
   float* dW = p.dW + (long long)g * p.sW + (long long)split * p.sSplit;
-  for (int n = 0; n < p.N; ++n) {
-    __syncthreads();
-    *reinterpret_cast<float4*>(&red[rl][cl][0]) = acc[n];
-    __syncthreads();
-    if (rl == 0 && col_ok) {
-      float4 s = *reinterpret_cast<float4*>(&red[0][cl][0]);
-      for (int k = 1; k < 16; ++k) {
-        const float4 t = *reinterpret_cast<float4*>(&red[k][cl][0]);
-        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  // compile-time n everywhere: a runtime index would push acc[] to scratch memory (7x slower)
+#pragma unroll
+  for (int n = 0; n < SKINNY_MAX_N; ++n) {
+    if (n < p.N) {  // block-uniform
+      __syncthreads();
+      *reinterpret_cast<float4*>(&red[rl][cl][0]) = acc[n];
+      __syncthreads();
+      if (rl == 0 && col_ok) {
+        float4 s = *reinterpret_cast<float4*>(&red[0][cl][0]);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+          const float4 t = *reinterpret_cast<float4*>(&red[k][cl][0]);
+          s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        *reinterpret_cast<float4*>(dW + (long long)n * p.ldk + col) = s;
       }
-      *reinterpret_cast<float4*>(dW + (long long)n * p.ldk + col) = s;
     }
   }
   if (blockIdx.x == 0) {

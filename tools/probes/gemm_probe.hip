@@ -96,6 +96,24 @@ int main(int argc, char** argv) {
     tot_us += us; tot_fl += flops;
   }
   printf("TOTAL %.1f us %.2f GFLOP %.1f TF/s\n", tot_us, tot_fl / 1e9, tot_fl / tot_us / 1e6);
+  {  // skinny last-layer kernels
+    struct Sk { const char* name; int kind, N, K, groups; };
+    for (Sk k : {Sk{"skinny fwd N=1 x2", 0, 1, 256, 2}, Sk{"skinny dx  N=1 x2", 1, 1, 256, 2}, Sk{"skinny dx  N=16 x1", 1, 16, 256, 1},
+                 Sk{"skinny dw  N=1 x2", 2, 1, 256, 2}, Sk{"skinny dw  N=16 x1", 2, 16, 256, 1}}) {
+      SkinnyP q = {};
+      q.X = A; q.ldx = k.K; q.sX = (long long)B * k.K; q.W = Bm; q.ldk = k.K; q.sW = 32 * 1024; q.bias = bias; q.sBias = 1024;
+      q.C = Cm; q.ldc = 32; q.sC = (long long)B * (k.kind == 1 ? k.K : 32); q.dY = aux; q.ldy = 32; q.sY = (long long)B * 32;
+      q.M = B; q.N = k.N; q.K = k.K; q.epi = k.kind == 1 ? SK_EPI_DELU : SK_EPI_NONE;
+      q.dW = Cm; q.dB = Cm + 16 * 2 * 512 * 512; q.sSplit = 2 * 512 * 512 + 2048; q.splits = 16;
+      q.rows_per_split = (int)pqlk_round_up((B + 15) / 16, 32);
+      float us = time_us([&] {
+        if (k.kind == 0) launch_skinny_fwd(q, k.groups, 0);
+        else if (k.kind == 1) launch_skinny_dx(q, k.groups, 0);
+        else launch_skinny_dw(q, k.groups, 0);
+      });
+      printf("%-22s %8.1f us\n", k.name, us);
+    }
+  }
   {  // two streams
     hipStream_t sa, sb; hipStreamCreate(&sa); hipStreamCreate(&sb);
     float* C2b = dalloc((size_t)2 * B * 512, 0.f);
