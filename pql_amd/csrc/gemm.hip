@@ -49,7 +49,7 @@ struct GemmP {
 
 #define KT_MAX 32   // reduction elements per LDS stage (template parameter KT: 32 or 16)
 #ifndef PQLK_KT
-#define PQLK_KT 32
+#define PQLK_KT 16   // 16: half the LDS per block -> a third block per CU; +3 % on the streamed learner step vs 32
 #endif
 // row stride of a k-contiguous tile = KT + 4 floats (36 or 20: odd multiple of 4 -> conflict-free b128 reads)
 
@@ -411,7 +411,9 @@ template <int MODE, int EPI>
 static int launch_tile(const GemmP& p, int gz, hipStream_t st) {
   const int ncols = (MODE == MODE_DW) ? p.N : p.ncols_store;
   const long long big = (long long)((p.M + 127) / 128) * ((ncols + 127) / 128) * gz;
+#if !defined(PQLK_FORCE_TILE64)   // tuning switch: everything on 64x64 tiles (more, smaller, better-interleaving blocks)
   if (big >= 256 && ncols >= 128 && EPI != EPI_DTANH_SLICE) return launch_gemm<MODE, 128, 128, EPI>(p, gz, st);
+#endif
   return launch_gemm<MODE, 64, 64, EPI>(p, gz, st);
 }
 
