@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--distl", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-streams", action="store_true", help="serialise V / P / rollout on one stream")
+    ap.add_argument("--no-fused", action="store_true", help="per-layer GEMM launches instead of the fused hidden-layer forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=96, help="schedule steps of the bounded CPU-oracle sample (~15 s)")
     ap.add_argument("--v-only", action="store_true", help="time free-running V-learner steps only")
@@ -76,7 +77,7 @@ def build_system(args, rank, world, device, pg):
     ov = [f"num_envs={args.num_envs}", f"task.name={args.task}", f"algo.batch_size={args.batch}",
           f"algo.memory_size={args.replay}", f"algo.nstep={args.nstep}", f"algo.distl={args.distl}",
           f"algo.v_learner_gpu={device.index}", f"algo.p_learner_gpu={device.index}", "algo.num_gpus=1",
-          f"algo.graph={not args.no_graph}", f"algo.streams={not args.no_streams}", f"sim_device=cuda:{device.index}",
+          f"algo.graph={not args.no_graph}", f"algo.streams={not args.no_streams}", f"algo.fused={not args.no_fused}", f"sim_device=cuda:{device.index}",
           f"device=cuda:{device.index}"]
     cfg = load_cfg(ov)
     cfg.algo.hidden_layers = hidden
@@ -166,13 +167,11 @@ def gemm_section_ms(v, iters=20):
     O = v.memory.ring.O
 
     def section():
-        L.check(L.lib.pqlk_mlp_forward(C.byref(al.desc), L.ptr(v.actor.arena.data), L.ptr(ws["xn_obs"]), ws["ld_o"], B,
-                                       L.ACT_TANH_NOISE, L.ptr(ws["draw"]), 0.8, 0.2, L.ptr(ws["acts_a"]),
-                                       L.ptr(ws["xn_sa"][:, O:]), ws["ld_sa"], st()))
-        L.check(L.lib.pqlk_mlp_forward(C.byref(cl.desc), L.ptr(v.critic_target.arena.data), L.ptr(ws["xn_sa"]), ws["ld_sa"], B,
-                                       L.ACT_NONE, None, 0.0, 0.0, L.ptr(ws["acts_t"]), None, 0, st()))
-        L.check(L.lib.pqlk_mlp_forward(C.byref(cl.desc), L.ptr(v.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
-                                       L.ACT_NONE, None, 0.0, 0.0, L.ptr(ws["acts_c"]), None, 0, st()))
+        from pql_amd.models.mlp import mlp_forward_raw
+        mlp_forward_raw(al, v.actor.arena.data, ws["xn_obs"], L.ACT_TANH_NOISE, ws["draw"], 0.8, 0.2, ws["acts_a"], ws["xn_sa"][:, O:],
+                        packed=v.pk_actor, stash_all=False)
+        mlp_forward_raw(cl, v.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"], packed=v.pk_target, stash_all=False)
+        mlp_forward_raw(cl, v.critic.arena.data, ws["x_sa"], L.ACT_NONE, acts=ws["acts_c"], packed=v.pk_critic, stash_all=True)
         L.check(L.lib.pqlk_mlp_backward(C.byref(cl.desc), L.ptr(v.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
                                         L.ptr(ws["acts_c"]), L.ptr(ws["dy"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0, 0,
                                         None, 0, L.ptr(ws["bwd"]), ws["bwd"].numel(), st()))
@@ -340,7 +339,7 @@ def main():
                                f"{args.replay} rows resident in HBM, batch {args.batch}, n-step {args.nstep}, "
                                f"{'DistributionalDoubleQ(51)' if args.distl else 'DoubleQ'} MLP {hidden}",
                    "schedule": "v_only" if args.v_only else "1 env-iteration : 4 P-steps : 8 V-steps",
-                   "graph": not args.no_graph, "streams": not args.no_streams, "parallelism": f"dp{world}" if world > 1 else "single"},
+                   "graph": not args.no_graph, "streams": not args.no_streams, "fused_forward": not args.no_fused, "parallelism": f"dp{world}" if world > 1 else "single"},
         "p_grad_steps_per_s": 0.0 if args.v_only else value / int(cfg.algo.critic_actor_ratio),
         "env_steps_per_s": 0.0 if args.v_only else value / int(cfg.algo.critic_sample_ratio) * args.num_envs,
         "gflop_per_v_step": f_v / 1e9, "gflop_per_p_step": f_p / 1e9,
@@ -349,7 +348,7 @@ def main():
         # roofline of the dominant kernel family: the fp32-MFMA GEMMs of one V step (k_gemm<...>)
         ms = gemm_section_ms(v)
         achieved = f_v / (ms * 1e-3) / 1e12
-        line["roofline"] = {"bound": "mfma", "kernel": "k_gemm (all fp32 v_mfma_f32_32x32x2 GEMM launches of one V-learner step)",
+        line["roofline"] = {"bound": "mfma", "kernel": "k_gemm + k_mlp_fwd_fused (all fp32 v_mfma_f32_32x32x2 launches of one V-learner step)",
                             "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "ms_per_launch_group": ms}
         gms = gather_ms(v)

@@ -153,6 +153,14 @@ int64_t pqlk_mlp_acts_floats(const PqlMlpDesc* d, int64_t b);             /* act
 int pqlk_mlp_act_offset(const PqlMlpDesc* d, int64_t b, int32_t net, int32_t layer, int64_t* off, int64_t* ld);
 int64_t pqlk_mlp_bwd_ws_floats(const PqlMlpDesc* d, int64_t b, int32_t splits); /* backward workspace */
 
+/* Fragment-ordered copy of the hidden layers' weights used by the fused forward path:
+ *   packed[net][layer < L-1][tile n/32][k/8][lane (r,h)][j] = W[32 tile + r][8 (k/8) + 4 h + j]
+ * pqlk_mlp_packed_floats() is 0 when the descriptor cannot take the fused path (a hidden width not a multiple of
+ * 32, or wider than 636 so that two 32-row LDS activation buffers exceed 160 KB).  Call pqlk_mlp_pack() whenever
+ * the arena changes (after the optimiser / Polyak step); it is one tiny launch per hidden layer. */
+int64_t pqlk_mlp_packed_floats(const PqlMlpDesc* d);
+int pqlk_mlp_pack(const PqlMlpDesc* d, const float* params, float* packed, pqlk_stream_t stream);
+
 /* Forward.  x: (B, ldx) with ldx >= pqlk_ld(dims[0]).  acts: stash of every layer's post-activation
  * output (layer l of net n at pqlk_mlp_act_offset).  The last layer's output gets `out_act`:
  *   NONE       : logits / Q values
@@ -160,8 +168,13 @@ int64_t pqlk_mlp_bwd_ws_floats(const PqlMlpDesc* d, int64_t b, int32_t splits); 
  *   TANH_NOISE : tanh, then target-policy smoothing a' = clamp(a + clamp(noise_std*draw, +-noise_clip), +-1)
  *                (pql/utils/noise.py:19-27 via pql_v_learner.py:63-71); draw: (B, dims[L]) contiguous N(0,1).
  * If out2 != NULL (n_nets must be 1) the final output is ALSO written to out2 with row stride ld_out2
- * (used to drop the actor's action into the action columns of a critic input: torch.cat for free). */
-int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+ * (used to drop the actor's action into the action columns of a critic input: torch.cat for free).
+ * packed != NULL (from pqlk_mlp_pack of the SAME params) selects the fused path: all hidden layers in one launch with
+ * the activations of a 32-row tile resident in LDS; results are identical to the per-layer path (same accumulation
+ * order).  stash_all = 0 on that path skips the HBM write of all but the last hidden layer (inference-only chains);
+ * backward needs stash_all = 1. */
+int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const float* packed, int32_t stash_all,
+                     const float* x, int64_t ldx, int64_t b,
                      int32_t out_act, const float* draw, float noise_std, float noise_clip,
                      float* acts, float* out2, int64_t ld_out2, pqlk_stream_t stream);
 

@@ -46,7 +46,9 @@ PROTOTYPES = {
     "pqlk_mlp_acts_floats": (_I64, [C.POINTER(PqlMlpDesc), _I64]),
     "pqlk_mlp_act_offset": (C.c_int, [C.POINTER(PqlMlpDesc), _I64, _I32, _I32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pqlk_mlp_bwd_ws_floats": (_I64, [C.POINTER(PqlMlpDesc), _I64, _I32]),
-    "pqlk_mlp_forward": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _I32, _P, _F, _F, _P, _P, _I64, _P]),
+    "pqlk_mlp_packed_floats": (_I64, [C.POINTER(PqlMlpDesc)]),
+    "pqlk_mlp_pack": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _P]),
+    "pqlk_mlp_forward": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I32, _P, _I64, _I64, _I32, _P, _F, _F, _P, _P, _I64, _P]),
     "pqlk_mlp_backward": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _P, _I64,
                                     _P, _I64, _P]),
     "pqlk_td_mse_loss": (C.c_int, [_P, _P, _I64, _P, _P, _F, _I64, _P, _P, _P, _I32, _P, _P]),

@@ -18,7 +18,7 @@ from pql_amd import _lib as L
 from pql_amd.algo.pql_actor import PQLActor
 from pql_amd.algo.pql_v_learner import LOSS_RING, _AdamState, _cfg_get, apply_optimizer
 from pql_amd.models import model_name_to_path
-from pql_amd.models.mlp import default_splits, output_view
+from pql_amd.models.mlp import default_splits, mlp_forward_raw, output_view
 from pql_amd.utils.common import load_class_from_path
 
 
@@ -94,14 +94,10 @@ class AgentDDPG(PQLActor):
             ws["x_obs"][:, :O].copy_(ws["x_sa"][:, :O])
             ws["x_pi"][:, :O].copy_(ws["x_sa"][:, :O])
             # ---- critic step (ddpg.py:147-157)
-            L.check(L.lib.pqlk_mlp_forward(C.byref(al.desc), L.ptr(self.actor.arena.data), L.ptr(ws["xn_obs"]), ws["ld_o"], B,
-                                           L.ACT_TANH_NOISE, L.ptr(draw), float(algo.noise.tgt_pol_std),
-                                           float(algo.noise.tgt_pol_noise_bound), L.ptr(ws["acts_a"]), L.ptr(ws["xn_sa"][:, O:]),
-                                           ws["ld_sa"], st))
-            L.check(L.lib.pqlk_mlp_forward(C.byref(cl.desc), L.ptr(self.critic_target.arena.data), L.ptr(ws["xn_sa"]), ws["ld_sa"], B,
-                                           L.ACT_NONE, None, 0.0, 0.0, L.ptr(ws["acts_t"]), None, 0, st))
-            L.check(L.lib.pqlk_mlp_forward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
-                                           L.ACT_NONE, None, 0.0, 0.0, L.ptr(ws["acts_c"]), None, 0, st))
+            mlp_forward_raw(al, self.actor.arena.data, ws["xn_obs"], L.ACT_TANH_NOISE, draw, algo.noise.tgt_pol_std,
+                            algo.noise.tgt_pol_noise_bound, ws["acts_a"], ws["xn_sa"][:, O:])
+            mlp_forward_raw(cl, self.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"])
+            mlp_forward_raw(cl, self.critic.arena.data, ws["x_sa"], L.ACT_NONE, acts=ws["acts_c"])
             q, qt = output_view(cl, ws["acts_c"], B), output_view(cl, ws["acts_t"], B)
             L.check(L.lib.pqlk_td_mse_loss(L.ptr(q), L.ptr(qt), cl.ld_out, L.ptr(ws["rew"]), L.ptr(ws["done"]),
                                            float(algo.gamma) ** int(algo.nstep), B, L.ptr(ws["dy"]), L.ptr(self.closs),
@@ -111,10 +107,8 @@ class AgentDDPG(PQLActor):
                                             L.ptr(ws["bwd_c"]), ws["bwd_c"].numel(), st))
             apply_optimizer(self.critic.arena.data, ws["gc"], self.copt, None, algo.critic_lr, algo.max_grad_norm, 0.0, 1.0, dev)
             # ---- actor step through the UPDATED critic (ddpg.py:159-166)
-            L.check(L.lib.pqlk_mlp_forward(C.byref(al.desc), L.ptr(self.actor.arena.data), L.ptr(ws["x_obs"]), ws["ld_o"], B,
-                                           L.ACT_TANH, None, 0.0, 0.0, L.ptr(ws["acts_a"]), L.ptr(ws["x_pi"][:, O:]), ws["ld_sa"], st))
-            L.check(L.lib.pqlk_mlp_forward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_pi"]), ws["ld_sa"], B,
-                                           L.ACT_NONE, None, 0.0, 0.0, L.ptr(ws["acts_c"]), None, 0, st))
+            mlp_forward_raw(al, self.actor.arena.data, ws["x_obs"], L.ACT_TANH, acts=ws["acts_a"], out2=ws["x_pi"][:, O:])
+            mlp_forward_raw(cl, self.critic.arena.data, ws["x_pi"], L.ACT_NONE, acts=ws["acts_c"])
             L.check(L.lib.pqlk_dpg_loss(L.ptr(output_view(cl, ws["acts_c"], B)), cl.ld_out, 1, None, B, L.ptr(ws["dy"]),
                                         L.ptr(self.aloss), L.ptr(self.aopt.step), LOSS_RING, L.ptr(ws["scratch"]), st))
             a_out = output_view(al, ws["acts_a"], B)

@@ -21,7 +21,7 @@ import torch
 from pql_amd import _lib as L
 from pql_amd.algo.pql_v_learner import LOSS_RING, LaggedLoss, _AdamState, _cfg_get, apply_optimizer, resident_norm
 from pql_amd.models import model_name_to_path
-from pql_amd.models.mlp import default_splits, output_view
+from pql_amd.models.mlp import PackedWeights, default_splits, mlp_forward_raw, output_view
 from pql_amd.replay.simple_replay import RecordRing, _obs_width, ring_plan
 from pql_amd.utils.common import Tracker, load_class_from_path
 
@@ -45,6 +45,9 @@ class PQLPLearner:
         if cfg.artifact is not None:
             raise NotImplementedError("W&B artifact download is out of scope (no network); load a local state_dict instead")
         self.opt = _AdamState(self.actor.arena.data)
+        self._fused = bool(_cfg_get(algo, "fused", True))
+        self.pk_actor = PackedWeights(self.actor.layout, self.device) if self._fused else None
+        self.pk_critic = None
         self.critic = None
 
         # obs-only replay (reference :32-37: a bare (memory_size, obs) tensor + inline pointer logic)
@@ -97,7 +100,14 @@ class PQLPLearner:
         ws["bwd_a"] = torch.empty(al.bwd_ws_floats(B, ws["splits"]), **f)
         ws["scratch"] = torch.zeros(2048, **f)
         self._ws = ws
+        self.repack()
         return ws
+
+    def repack(self):
+        if self.pk_actor is not None:
+            self.pk_actor.refresh(self.actor.arena.data)
+        if self.pk_critic is not None:
+            self.pk_critic.refresh(self.critic.arena.data)
 
     def _step_kernels(self, ws, idx):
         algo, dev, B = self.cfg.algo, self.device, ws["B"]
@@ -111,10 +121,10 @@ class PQLPLearner:
                                                st))
         al, cl = self.actor.layout, self.critic.layout
         x_act = ws["x_sa"][:, O:]
-        L.check(L.lib.pqlk_mlp_forward(C.byref(al.desc), L.ptr(self.actor.arena.data), L.ptr(ws["x_obs"]), ws["ld_o"], B,
-                                       L.ACT_TANH, None, 0.0, 0.0, L.ptr(ws["acts_a"]), L.ptr(x_act), ws["ld_sa"], st))
-        L.check(L.lib.pqlk_mlp_forward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
-                                       L.ACT_NONE, None, 0.0, 0.0, L.ptr(ws["acts_c"]), None, 0, st))
+        mlp_forward_raw(al, self.actor.arena.data, ws["x_obs"], L.ACT_TANH, acts=ws["acts_a"], out2=x_act, packed=self.pk_actor,
+                        stash_all=True)
+        mlp_forward_raw(cl, self.critic.arena.data, ws["x_sa"], L.ACT_NONE, acts=ws["acts_c"], packed=self.pk_critic,
+                        stash_all=True)   # the dX chain through the frozen critic needs its activations (ELU')
         q = output_view(cl, ws["acts_c"], B)
         K = int(getattr(self.critic, "num_atoms", 1))
         z = getattr(self.critic, "z_atoms", None) if K > 1 else None
@@ -131,6 +141,8 @@ class PQLPLearner:
             torch.distributed.all_reduce(ws["grads"], group=self.pg)
         apply_optimizer(self.actor.arena.data, ws["grads"], self.opt, None, algo.actor_lr, algo.max_grad_norm, 0.0,
                         1.0 / self.world, dev)
+        if self.pk_actor is not None:
+            self.pk_actor.refresh(self.actor.arena.data)
 
     def _draw_and_step(self, ws):
         ws["idx"].copy_(torch.randint(self.cur_capacity, size=(ws["B"],), device=self.device))  # the only draw (:49)
@@ -168,6 +180,7 @@ class PQLPLearner:
         torch.cuda.current_stream(self.device).wait_stream(s)
         for dst, src in zip(self._state(), snap):
             dst.copy_(src)
+        self.repack()
         torch.cuda.set_rng_state(rng, self.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -193,8 +206,11 @@ class PQLPLearner:
             if hasattr(self.critic, "z_atoms"):
                 self.critic.z_atoms = self.critic.z_atoms.to(self.device)
                 self.critic.device = self.device
+            self.pk_critic = PackedWeights(self.critic.layout, self.device) if self._fused else None
         elif critic is not self.critic:
             self.critic.arena.data.copy_(critic.arena.data, non_blocking=True)
+        if self.pk_critic is not None:
+            self.pk_critic.refresh(self.critic.arena.data)
 
     @torch.no_grad()
     def update(self, critic, obs, normalize_tuple, sleep_time):

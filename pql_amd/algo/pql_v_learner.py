@@ -23,7 +23,7 @@ import torch
 
 from pql_amd import _lib as L
 from pql_amd.models import model_name_to_path
-from pql_amd.models.mlp import default_splits, output_view
+from pql_amd.models.mlp import PackedWeights, default_splits, mlp_forward_raw, output_view
 from pql_amd.replay.simple_replay import ReplayBuffer
 from pql_amd.utils.common import Tracker, load_class_from_path
 
@@ -131,6 +131,11 @@ class PQLVLearner:
             raise NotImplementedError("W&B artifact download is out of scope (no network); load a local state_dict instead")
         self.critic_target = deepcopy(self.critic)
         self.opt = _AdamState(self.critic.arena.data)
+        fused = bool(_cfg_get(algo, "fused", True))
+        self.pk_critic = PackedWeights(self.critic.layout, self.device) if fused else None
+        self.pk_target = PackedWeights(self.critic.layout, self.device) if fused else None
+        self.pk_actor = None
+        self._fused = fused
         self.actor = None
         self.memory = ReplayBuffer(capacity=int(algo.memory_size), obs_dim=self.obs_dim, action_dim=self.action_dim,
                                    device=self.device)
@@ -178,7 +183,16 @@ class PQLVLearner:
         ws["bwd"] = torch.empty(cl.bwd_ws_floats(B, ws["splits"]), **f)
         ws["scratch"] = torch.zeros(2048, **f)
         self._ws = ws
+        self.repack()
         return ws
+
+    def repack(self):
+        """Re-derive the fragment-ordered weight copies from the arenas (after loading a state_dict etc.)."""
+        if self._fused:
+            self.pk_critic.refresh(self.critic.arena.data)
+            self.pk_target.refresh(self.critic_target.arena.data)
+            if self.pk_actor is not None:
+                self.pk_actor.refresh(self.actor.arena.data)
 
     def _norm_ptrs(self):
         if not self.cfg.algo.obs_norm or self.normalize_tuple is None:
@@ -196,16 +210,15 @@ class PQLVLearner:
                                                L.ptr(ws["x_sa"]), ws["ld_sa"], L.ptr(ws["xn_sa"]), L.ptr(ws["xn_obs"]),
                                                ws["ld_o"], L.ptr(ws["rew"]), L.ptr(ws["done"]), st))
         al, cl = self.actor.layout, self.critic.layout
-        # target policy smoothing (:63-71): a' written into the action columns of the target critic's input
+        # target policy smoothing (:63-71): a' written into the action columns of the target critic's input.
+        # The two no-grad chains (actor, target critic) skip the activation stash; the critic keeps it for backward.
         xn_act = ws["xn_sa"][:, O:]
-        L.check(L.lib.pqlk_mlp_forward(C.byref(al.desc), L.ptr(self.actor.arena.data), L.ptr(ws["xn_obs"]), ws["ld_o"], B,
-                                       L.ACT_TANH_NOISE, L.ptr(draw), float(algo.noise.tgt_pol_std),
-                                       float(algo.noise.tgt_pol_noise_bound), L.ptr(ws["acts_a"]), L.ptr(xn_act),
-                                       ws["ld_sa"], st))
-        L.check(L.lib.pqlk_mlp_forward(C.byref(cl.desc), L.ptr(self.critic_target.arena.data), L.ptr(ws["xn_sa"]),
-                                       ws["ld_sa"], B, L.ACT_NONE, None, 0.0, 0.0, L.ptr(ws["acts_t"]), None, 0, st))
-        L.check(L.lib.pqlk_mlp_forward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
-                                       L.ACT_NONE, None, 0.0, 0.0, L.ptr(ws["acts_c"]), None, 0, st))
+        mlp_forward_raw(al, self.actor.arena.data, ws["xn_obs"], L.ACT_TANH_NOISE, draw, algo.noise.tgt_pol_std,
+                        algo.noise.tgt_pol_noise_bound, ws["acts_a"], xn_act, packed=self.pk_actor, stash_all=False)
+        mlp_forward_raw(cl, self.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"], packed=self.pk_target,
+                        stash_all=False)
+        mlp_forward_raw(cl, self.critic.arena.data, ws["x_sa"], L.ACT_NONE, acts=ws["acts_c"], packed=self.pk_critic,
+                        stash_all=True)
         q = output_view(cl, ws["acts_c"], B)
         qt = output_view(cl, ws["acts_t"], B)
         gamma_n = float(algo.gamma) ** int(algo.nstep)
@@ -225,6 +238,8 @@ class PQLVLearner:
             torch.distributed.all_reduce(ws["grads"], group=self.pg)
         apply_optimizer(self.critic.arena.data, ws["grads"], self.opt, self.critic_target.arena.data, algo.critic_lr,
                         algo.max_grad_norm, algo.tau, 1.0 / self.world, dev)
+        self.pk_critic.refresh(self.critic.arena.data)          # fragment-ordered copies follow the new weights
+        self.pk_target.refresh(self.critic_target.arena.data)
 
     def _draw_and_step(self, ws):
         B = ws["B"]
@@ -285,6 +300,7 @@ class PQLVLearner:
         for dst, src in zip((self.critic.arena.data, self.critic_target.arena.data, self.opt.m, self.opt.v, self.opt.step,
                              self.loss_ring), tensors):
             dst.copy_(src)
+        self.repack()
         torch.cuda.set_rng_state(rng, self.device)
 
     # ------------------------------------------------------------------------------------------
@@ -303,8 +319,11 @@ class PQLVLearner:
         over xGMI) into a resident replica instead of re-materialising a module."""
         if self.actor is None or self.actor.layout.dims != actor.layout.dims:
             self.actor = deepcopy(actor).to(self.device)
+            self.pk_actor = PackedWeights(self.actor.layout, self.device) if self._fused else None
         elif actor is not self.actor:
             self.actor.arena.data.copy_(actor.arena.data, non_blocking=True)
+        if self.pk_actor is not None:
+            self.pk_actor.refresh(self.actor.arena.data)
 
     @torch.no_grad()
     def update(self, actor, trajectory, normalize_tuple, sleep_time):

@@ -18,6 +18,7 @@
 // this one lets k-contiguous operands be fetched with one ds_read_b128 per four MFMAs.
 #include "pqlk_common.h"
 #include "skinny.h"
+#include "fused.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -497,9 +498,86 @@ extern "C" int64_t pqlk_mlp_bwd_ws_floats(const PqlMlpDesc* d, int64_t b, int32_
 }
 
 // ================================================================================================
-extern "C" int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
-                                int32_t out_act, const float* draw, float noise_std, float noise_clip, float* acts,
-                                float* out2, int64_t ld_out2, pqlk_stream_t stream) {
+// fused hidden-layer path (fused.h)
+static bool fusable(const PqlMlpDesc* d, int* buf_ld_out) {
+  if (d->n_layers < 2) return false;
+  int64_t w = pqlk_ld(d->dims[0]);
+  for (int l = 1; l < d->n_layers; ++l) {
+    if (d->dims[l] % 32 != 0) return false;
+    w = d->dims[l] > w ? d->dims[l] : w;
+  }
+  const int64_t buf_ld = w + 4;
+  if (2 * 32 * buf_ld * (int64_t)sizeof(float) > 160 * 1024) return false;
+  if (buf_ld_out) *buf_ld_out = (int)buf_ld;
+  return true;
+}
+
+static int64_t packed_net_stride(const PqlMlpDesc* d) {
+  int64_t n = 0;
+  for (int l = 0; l + 1 < d->n_layers; ++l) n += (int64_t)d->dims[l + 1] * pqlk_ld(d->dims[l]);
+  return n;
+}
+
+extern "C" int64_t pqlk_mlp_packed_floats(const PqlMlpDesc* d) {
+  if (desc_ok(d) || !fusable(d, nullptr)) return 0;
+  return packed_net_stride(d) * d->n_nets;
+}
+
+extern "C" int pqlk_mlp_pack(const PqlMlpDesc* d, const float* params, float* packed, pqlk_stream_t stream) {
+  int rc = desc_ok(d);
+  if (rc) return rc;
+  PQLK_REQUIRE(params && packed, PQLK_E_NULL);
+  PQLK_REQUIRE(fusable(d, nullptr), PQLK_E_UNSUPPORTED);
+  const int64_t net_stride = pqlk_mlp_net_stride(d), pstride = packed_net_stride(d);
+  int64_t p_off = 0;
+  for (int l = 0; l + 1 < d->n_layers; ++l) {
+    int64_t w_off, b_off;
+    pqlk_mlp_layer_offsets(d, l, &w_off, &b_off);
+    const int N = d->dims[l + 1], K = (int)pqlk_ld(d->dims[l]);
+    int blocks = (int)(((int64_t)N * K + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_mlp_pack, dim3(blocks, d->n_nets), dim3(256), 0, pqlk_s(stream), params, packed, (long long)w_off,
+                       (long long)p_off, N, K, K, (long long)net_stride, (long long)pstride);
+    PQLK_LAUNCH_CHECK();
+    p_off += (int64_t)N * K;
+  }
+  return PQLK_OK;
+}
+
+static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const float* packed, const float* x, int64_t ldx,
+                               int64_t b, float* acts, int stash_all, hipStream_t st) {
+  FusedP p = {};
+  int buf_ld = 0;
+  if (!fusable(d, &buf_ld)) return PQLK_E_UNSUPPORTED;
+  p.X = x; p.params = params; p.packed = packed; p.acts = acts;
+  p.B = (int)b; p.ldx = (int)ldx; p.n_hidden = d->n_layers - 1; p.stash_all = stash_all; p.buf_ld = buf_ld;
+  p.net_stride = pqlk_mlp_net_stride(d); p.packed_net_stride = packed_net_stride(d);
+  int64_t p_off = 0;
+  for (int l = 0; l <= d->n_layers; ++l) p.dims[l] = d->dims[l];
+  for (int l = 0; l + 1 < d->n_layers; ++l) {
+    int64_t w_off, b_off, a_off, a_ld;
+    pqlk_mlp_layer_offsets(d, l, &w_off, &b_off);
+    pqlk_mlp_act_offset(d, b, 0, l, &a_off, &a_ld);
+    p.b_off[l] = b_off; p.p_off[l] = p_off; p.a_off[l] = a_off;
+    p_off += (int64_t)d->dims[l + 1] * pqlk_ld(d->dims[l]);
+  }
+  const size_t shmem = (size_t)2 * 32 * buf_ld * sizeof(float);
+  static size_t attr_set = 0;
+  if (shmem > attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024);
+    if (e != hipSuccess) return -(int)e;
+    attr_set = 160 * 1024;
+  }
+  hipLaunchKernelGGL(k_mlp_fwd_fused, dim3((unsigned)((b + 31) / 32), d->n_nets), dim3(256), shmem, st, p);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}
+
+// ================================================================================================
+extern "C" int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const float* packed, int32_t stash_all,
+                                const float* x, int64_t ldx, int64_t b, int32_t out_act, const float* draw, float noise_std,
+                                float noise_clip, float* acts, float* out2, int64_t ld_out2, pqlk_stream_t stream) {
   int rc = desc_ok(d);
   if (rc) return rc;
   PQLK_REQUIRE(params && x && acts, PQLK_E_NULL);
@@ -511,7 +589,14 @@ extern "C" int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const 
   if (out2) PQLK_REQUIRE(d->n_nets == 1 && ld_out2 >= d->dims[d->n_layers], PQLK_E_SHAPE);
   const int64_t net_stride = pqlk_mlp_net_stride(d);
   const int L = d->n_layers;
-  for (int l = 0; l < L; ++l) {
+  int l_first = 0;
+  if (packed && fusable(d, nullptr)) {  // all hidden layers in one launch, activations resident in LDS
+    PQLK_REQUIRE(pqlk_aligned16(packed), PQLK_E_ALIGN);
+    rc = launch_fused_hidden(d, params, packed, x, ldx, b, acts, stash_all ? 1 : 0, pqlk_s(stream));
+    if (rc) return rc;
+    l_first = L - 1;
+  }
+  for (int l = l_first; l < L; ++l) {
     int64_t w_off, b_off, a_off, a_ld;
     pqlk_mlp_layer_offsets(d, l, &w_off, &b_off);
     pqlk_mlp_act_offset(d, b, 0, l, &a_off, &a_ld);

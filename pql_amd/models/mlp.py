@@ -88,17 +88,35 @@ def pad_cols(x: torch.Tensor, ld: int) -> torch.Tensor:
     return out
 
 
+class PackedWeights:
+    """Fragment-ordered copy of an arena's hidden-layer weights for the fused forward kernel (pqlk_mlp_pack).
+    `tensor` is None when the layout cannot take the fused path (then forward falls back to per-layer GEMMs).
+    refresh() must run after every change of the arena (optimiser step, Polyak, weight hand-off)."""
+
+    def __init__(self, layout: ArenaLayout, device):
+        n = int(L.lib.pqlk_mlp_packed_floats(C.byref(layout.desc)))
+        self.layout = layout
+        self.tensor = torch.zeros(n, dtype=torch.float32, device=device) if n > 0 else None
+
+    def refresh(self, arena):
+        if self.tensor is not None:
+            L.check(L.lib.pqlk_mlp_pack(C.byref(self.layout.desc), L.ptr(arena), L.ptr(self.tensor), L.stream(arena.device)))
+        return self
+
+
 def mlp_forward_raw(layout: ArenaLayout, arena, x_pad, out_act=L.ACT_NONE, draw=None, noise_std=0.0, noise_clip=0.0,
-                    acts=None, out2=None):
-    """Launch the forward; returns the activation stash (last block = (n_nets, B, ld_out) output)."""
+                    acts=None, out2=None, packed: PackedWeights = None, stash_all=True):
+    """Launch the forward; returns the activation stash (last block = (n_nets, B, ld_out) output).
+    packed: PackedWeights refreshed from `arena` -> fused hidden layers; None -> one GEMM launch per layer."""
     B = x_pad.shape[0]
     dev = x_pad.device
     if acts is None:
         acts = torch.empty(layout.acts_floats(B), dtype=torch.float32, device=dev)
+    pk = packed.tensor if packed is not None else None
     with torch.cuda.device(dev):
-        L.check(L.lib.pqlk_mlp_forward(C.byref(layout.desc), L.ptr(arena), L.ptr(x_pad), x_pad.stride(0), B, out_act,
-                                       L.ptr(draw), noise_std, noise_clip, L.ptr(acts),
-                                       L.ptr(out2), out2.stride(0) if out2 is not None else 0, L.stream(dev)))
+        L.check(L.lib.pqlk_mlp_forward(C.byref(layout.desc), L.ptr(arena), L.ptr(pk), 1 if stash_all else 0, L.ptr(x_pad),
+                                       x_pad.stride(0), B, out_act, L.ptr(draw), float(noise_std), float(noise_clip),
+                                       L.ptr(acts), L.ptr(out2), out2.stride(0) if out2 is not None else 0, L.stream(dev)))
     return acts
 
 

@@ -408,3 +408,37 @@ def test_batch_moments(dev):
     bm, bv = rms.batch_moments(x.to(dev))
     np.testing.assert_allclose(bm.cpu().numpy(), x.mean(0).numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(bv.cpu().numpy(), x.var(0).numpy(), rtol=1e-5)
+
+
+# --------------------------------------------------------------------------- fused hidden-layer forward
+@pytest.mark.parametrize("dims,nets,B", [([104, 512, 512, 256, 1], 2, 8192), ([88, 512, 256, 128, 16], 1, 777),
+                                          ([231, 512, 256, 128, 51], 2, 100), ([10, 32, 64, 2], 1, 33)])
+def test_fused_forward_equals_per_layer_path(dev, dims, nets, B):
+    """k_mlp_fwd_fused (activations resident in LDS, fragment-ordered weights) accumulates every element in the same
+    order as the per-layer k_gemm path: outputs and every stashed activation must be bit-identical."""
+    from pql_amd import _lib as L
+    from pql_amd.models.mlp import ArenaLayout, PackedWeights, mlp_forward_raw, output_view
+    lay = ArenaLayout(dims, nets)
+    arena = torch.zeros(lay.total, device=dev)
+    for n in range(nets):
+        for l in range(lay.n_layers):
+            bound = 1.0 / np.sqrt(dims[l])
+            lay.weight(arena, n, l).copy_(T(dd.uniform((dims[l + 1], dims[l]), 100 * n + l, -bound, bound)))
+            lay.bias(arena, n, l).copy_(T(dd.uniform((dims[l + 1],), 100 * n + l + 50, -bound, bound)))
+    x = torch.zeros((B, lay.ld_in), device=dev)
+    x[:, : dims[0]] = T(dd.uniform((B, dims[0]), 7, -2, 2)).to(dev)
+    pk = PackedWeights(lay, dev)
+    assert pk.tensor is not None and pk.tensor.numel() == nets * sum(dims[l + 1] * L.ld(dims[l]) for l in range(lay.n_layers - 1))
+    pk.refresh(arena)
+    a_ref = mlp_forward_raw(lay, arena, x, L.ACT_NONE)
+    a_fused = mlp_forward_raw(lay, arena, x, L.ACT_NONE, packed=pk, stash_all=True)
+    assert torch.equal(a_ref, a_fused)
+    a_inf = mlp_forward_raw(lay, arena, x, L.ACT_NONE, packed=pk, stash_all=False)   # inference: only the tail is stashed
+    assert torch.equal(output_view(lay, a_inf, B), output_view(lay, a_ref, B))
+
+
+def test_fused_path_is_declined_for_unsupported_widths(dev):
+    from pql_amd.models.mlp import ArenaLayout, PackedWeights
+    assert PackedWeights(ArenaLayout([8, 100, 64, 1], 1), dev).tensor is None      # hidden width not a multiple of 32
+    assert PackedWeights(ArenaLayout([8, 1024, 1024, 1], 1), dev).tensor is None   # two LDS activation buffers > 160 KB
+    assert PackedWeights(ArenaLayout([8, 1], 1), dev).tensor is None               # no hidden layer
