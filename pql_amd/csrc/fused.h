@@ -32,8 +32,13 @@ struct FusedP {
 
 __device__ __forceinline__ float fused_elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
+// in_off / out_off: float offsets of the two activation buffers inside the dynamic LDS array.  They are passed as
+// OFFSETS, not pointers: a runtime-selected pointer loses its address space, the reads become flat_load and every
+// wait degrades to `vmcnt(0) lgkmcnt(0)`, which drains the weight prefetch ring on each k-step.
+extern __shared__ __attribute__((aligned(16))) float fsm[];
+
 template <int TPW>
-__device__ __forceinline__ void fused_layer(const float* __restrict__ in_lds, float* __restrict__ out_lds, int buf_ld, int K,
+__device__ __forceinline__ void fused_layer(int in_off, int out_off, int buf_ld, int K,
                                             int N, const float* __restrict__ packed_l, const float* __restrict__ bias_l,
                                             float* __restrict__ gout, int g_ld, int row0, int B, int wave, int lane) {
   const int r = lane & 31, h = lane >> 5;
@@ -52,11 +57,12 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ in_lds, fl
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int j = 0; j < TPW; ++j) bq[s][j] = s < K8 ? wp[j][s * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int j = 0; j < TPW; ++j) bq[s][j] = wp[j][s * 64];   // K8 >= 4
+    __builtin_amdgcn_sched_barrier(0);
     for (int k8 = 0; k8 < K8; k8 += 4) {  // K is a multiple of 32 -> K8 a multiple of 4
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const float4 a = *reinterpret_cast<const float4*>(in_lds + r * buf_ld + 8 * (k8 + s) + 4 * h);
+        const float4 a = *reinterpret_cast<const float4*>(&fsm[in_off + r * buf_ld + 8 * (k8 + s) + 4 * h]);
         const float av[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
@@ -64,10 +70,12 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ in_lds, fl
 #pragma unroll
           for (int t = 0; t < 4; ++t) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t], av[t], acc[j], 0, 0, 0);
         }
-        if (k8 + s + 4 < K8) {
+        // unconditional refill (index clamped at the tail): straight-line code lets the compiler keep the other
+        // three ring stages in flight behind a counted s_waitcnt vmcnt(N); a branch here degrades every wait to vmcnt(0)
+        const int kn = min(k8 + s + 4, K8 - 1);
 #pragma unroll
-          for (int j = 0; j < TPW; ++j) bq[s][j] = wp[j][(k8 + s + 4) * 64];
-        }
+        for (int j = 0; j < TPW; ++j) bq[s][j] = wp[j][kn * 64];
+        __builtin_amdgcn_sched_barrier(0);  // keep the refill HERE: hipcc otherwise sinks the loads to just before use
       }
     }
     // epilogue: lane (r, h) owns row r, columns 32*tile + 8q + 4h + {0..3} (transposed-tile accumulator layout)
@@ -83,7 +91,7 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ in_lds, fl
         v.y = fused_elu(acc[j][4 * q + 1] + b4.y);
         v.z = fused_elu(acc[j][4 * q + 2] + b4.z);
         v.w = fused_elu(acc[j][4 * q + 3] + b4.w);
-        *reinterpret_cast<float4*>(out_lds + r * buf_ld + col) = v;
+        *reinterpret_cast<float4*>(&fsm[out_off + r * buf_ld + col]) = v;
         if (gout && row_ok) *reinterpret_cast<float4*>(gout + (long long)(row0 + r) * g_ld + col) = v;
       }
     }
@@ -91,10 +99,9 @@ __device__ __forceinline__ void fused_layer(const float* __restrict__ in_lds, fl
 }
 
 __global__ __launch_bounds__(256) void k_mlp_fwd_fused(FusedP p) {
-  extern __shared__ __attribute__((aligned(16))) float fsm[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row0 = blockIdx.x * 32, net = blockIdx.y;
-  float* buf[2] = {fsm, fsm + 32 * p.buf_ld};
+  const int boff[2] = {0, 32 * p.buf_ld};
   {  // stage the input tile (pad columns of X are zero by contract; rows past B are zero-filled)
     const int k0 = (p.dims[0] + 31) & ~31;
     const int cpr = k0 >> 2;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_fused(FusedP p) {
       const int row = i / cpr, c4 = i % cpr;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row0 + row < p.B) v = *reinterpret_cast<const float4*>(p.X + (long long)(row0 + row) * p.ldx + 4 * c4);
-      *reinterpret_cast<float4*>(buf[0] + row * p.buf_ld + 4 * c4) = v;
+      *reinterpret_cast<float4*>(&fsm[row * p.buf_ld + 4 * c4]) = v;
     }
   }
   __syncthreads();
@@ -112,8 +119,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_fused(FusedP p) {
     const float* bias_l = p.params + (long long)net * p.net_stride + p.b_off[l];
     float* gout = (p.stash_all || l == p.n_hidden - 1) ? p.acts + p.a_off[l] + (long long)net * p.B * N : nullptr;
     const int ntiles = N >> 5;
-    const float* in = buf[l & 1];
-    float* out = buf[(l & 1) ^ 1];
+    const int in = boff[l & 1], out = boff[(l & 1) ^ 1];
     if ((ntiles & 15) == 0) fused_layer<4>(in, out, p.buf_ld, K, N, packed_l, bias_l, gout, N, row0, p.B, wave, lane);
     else if ((ntiles & 7) == 0) fused_layer<2>(in, out, p.buf_ld, K, N, packed_l, bias_l, gout, N, row0, p.B, wave, lane);
     else fused_layer<1>(in, out, p.buf_ld, K, N, packed_l, bias_l, gout, N, row0, p.B, wave, lane);
