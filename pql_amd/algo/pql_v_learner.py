@@ -238,8 +238,9 @@ class PQLVLearner:
             torch.distributed.all_reduce(ws["grads"], group=self.pg)
         apply_optimizer(self.critic.arena.data, ws["grads"], self.opt, self.critic_target.arena.data, algo.critic_lr,
                         algo.max_grad_norm, algo.tau, 1.0 / self.world, dev)
-        self.pk_critic.refresh(self.critic.arena.data)          # fragment-ordered copies follow the new weights
-        self.pk_target.refresh(self.critic_target.arena.data)
+        if self._fused:   # fragment-ordered copies follow the new weights
+            self.pk_critic.refresh(self.critic.arena.data)
+            self.pk_target.refresh(self.critic_target.arena.data)
 
     def _draw_and_step(self, ws):
         B = ws["B"]

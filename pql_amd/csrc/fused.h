@@ -24,7 +24,7 @@ struct FusedP {
   const float* params;  // parameter arena (biases are read from here)
   const float* packed;  // fragment-ordered hidden-layer weights
   float* acts;          // activation stash (layout of pqlk_mlp_act_offset)
-  int B, ldx, n_hidden, stash_all, buf_ld;
+  int B, ldx, n_hidden, stash_all, buf_ld, n_nets;
   int dims[PQLK_MAX_LAYERS + 1];  // in (logical), h1, h2, ...
   long long net_stride, packed_net_stride;
   long long b_off[PQLK_MAX_LAYERS], p_off[PQLK_MAX_LAYERS], a_off[PQLK_MAX_LAYERS];
@@ -100,7 +100,21 @@ __device__ __forceinline__ void fused_layer(int in_off, int out_off, int buf_ld,
 
 __global__ __launch_bounds__(256) void k_mlp_fwd_fused(FusedP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int row0 = blockIdx.x * 32, net = blockIdx.y;
+  // XCD-aware block -> (net, row tile) map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share
+  // an L2), and a twin critic's fragment-ordered weights are 2 x 1.8 MB against a 4 MB L2: with both nets on every
+  // XCD the weight stream thrashes L2 and falls back to the Infinity Cache.  Even XCD groups take net 0, odd ones
+  // net 1, so each L2 keeps ONE net's weights resident.  (Speed only: any placement computes the same result.)
+  int net, tile;
+  const int tiles = (p.B + 31) >> 5;
+  if (p.n_nets == 2 && (tiles & 3) == 0) {
+    const int b = blockIdx.x, g = b & 7, i = b >> 3;
+    net = g & 1;
+    tile = i * 4 + (g >> 1);
+  } else {
+    net = blockIdx.x / tiles;
+    tile = blockIdx.x % tiles;
+  }
+  const int row0 = tile * 32;
   const int boff[2] = {0, 32 * p.buf_ld};
   {  // stage the input tile (pad columns of X are zero by contract; rows past B are zero-filled)
     const int k0 = (p.dims[0] + 31) & ~31;

@@ -550,7 +550,7 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
   int buf_ld = 0;
   if (!fusable(d, &buf_ld)) return PQLK_E_UNSUPPORTED;
   p.X = x; p.params = params; p.packed = packed; p.acts = acts;
-  p.B = (int)b; p.ldx = (int)ldx; p.n_hidden = d->n_layers - 1; p.stash_all = stash_all; p.buf_ld = buf_ld;
+  p.B = (int)b; p.ldx = (int)ldx; p.n_hidden = d->n_layers - 1; p.stash_all = stash_all; p.buf_ld = buf_ld; p.n_nets = d->n_nets;
   p.net_stride = pqlk_mlp_net_stride(d); p.packed_net_stride = packed_net_stride(d);
   int64_t p_off = 0;
   for (int l = 0; l <= d->n_layers; ++l) p.dims[l] = d->dims[l];
@@ -569,7 +569,7 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
     if (e != hipSuccess) return -(int)e;
     attr_set = 160 * 1024;
   }
-  hipLaunchKernelGGL(k_mlp_fwd_fused, dim3((unsigned)((b + 31) / 32), d->n_nets), dim3(256), shmem, st, p);
+  hipLaunchKernelGGL(k_mlp_fwd_fused, dim3((unsigned)(((b + 31) / 32) * d->n_nets)), dim3(256), shmem, st, p);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }

@@ -96,6 +96,24 @@ int main(int argc, char** argv) {
     tot_us += us; tot_fl += flops;
   }
   printf("TOTAL %.1f us %.2f GFLOP %.1f TF/s\n", tot_us, tot_fl / 1e9, tot_fl / tot_us / 1e6);
+  {  // fused hidden-layer forward vs the per-layer path, twin critic 128->512->512->256->1 and actor 96->..->16
+    for (int cfg = 0; cfg < 2; ++cfg) {
+      PqlMlpDesc d = {};
+      d.n_layers = 4; d.n_nets = cfg == 0 ? 2 : 1;
+      const int dm0[5] = {104, 512, 512, 256, 1}, dm1[5] = {88, 512, 512, 256, 16};
+      for (int i = 0; i < 5; ++i) d.dims[i] = cfg == 0 ? dm0[i] : dm1[i];
+      float* params = dalloc(pqlk_mlp_param_floats(&d), 0.05f);
+      float* packed = dalloc(pqlk_mlp_packed_floats(&d), 0.f);
+      float* acts = dalloc(pqlk_mlp_acts_floats(&d, B), 0.f);
+      float* x = dalloc((size_t)B * 128, 1.f);
+      pqlk_mlp_pack(&d, params, packed, 0);
+      float u0 = time_us([&] { pqlk_mlp_forward(&d, params, nullptr, 1, x, 128, B, 0, nullptr, 0, 0, acts, nullptr, 0, 0); });
+      float u1 = time_us([&] { pqlk_mlp_forward(&d, params, packed, 1, x, 128, B, 0, nullptr, 0, 0, acts, nullptr, 0, 0); });
+      float u2 = time_us([&] { pqlk_mlp_forward(&d, params, packed, 0, x, 128, B, 0, nullptr, 0, 0, acts, nullptr, 0, 0); });
+      float u3 = time_us([&] { pqlk_mlp_pack(&d, params, packed, 0); });
+      printf("mlp fwd nets=%d: per-layer %.1f us | fused+stash %.1f us | fused no-stash %.1f us | pack %.1f us\n", d.n_nets, u0, u1, u2, u3);
+    }
+  }
   {  // skinny last-layer kernels
     struct Sk { const char* name; int kind, N, K, groups; };
     for (Sk k : {Sk{"skinny fwd N=1 x2", 0, 1, 256, 2}, Sk{"skinny dx  N=1 x2", 1, 1, 256, 2}, Sk{"skinny dx  N=16 x1", 1, 16, 256, 1},
