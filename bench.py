@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=96, help="schedule steps of the bounded CPU-oracle sample (~15 s)")
     ap.add_argument("--v-only", action="store_true", help="time free-running V-learner steps only")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' + --share-gpu rehearses the DP path on one GPU")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -88,7 +90,10 @@ def build_system(args, rank, world, device, pg):
     p = PQLPLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=pg)
     if world > 1:   # replicated parameters: every rank starts from rank 0's weights
         for t in (v.critic.arena.data, p.actor.arena.data):
-            torch.distributed.broadcast(t, src=0, group=pg)
+            if torch.distributed.get_backend(pg) == "gloo":
+                h = t.cpu(); torch.distributed.broadcast(h, src=0, group=pg); t.copy_(h)
+            else:
+                torch.distributed.broadcast(t, src=0, group=pg)
         v.critic_target.arena.data.copy_(v.critic.arena.data)
         actor.obs_rms.pg = pg
     return cfg, env, actor, v, p
@@ -283,11 +288,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
-    device = torch.device(f"cuda:{local}")
+    device = torch.device("cuda:0" if args.share_gpu else f"cuda:{local}")
     torch.cuda.set_device(device)
     pg = None
     if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=device)   # RCCL
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device)   # RCCL
+        else:
+            torch.distributed.init_process_group(args.backend)
         pg = torch.distributed.group.WORLD
     torch.manual_seed(42 + rank)
 
@@ -320,7 +328,7 @@ def main():
     dt = time.perf_counter() - t0
     note(f"timed {args.steps} steps in {dt:.3f} s")
     if world > 1:
-        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        tt = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX, group=pg)
         dt = float(tt.item())
 

@@ -19,7 +19,7 @@ from copy import deepcopy
 import torch
 
 from pql_amd import _lib as L
-from pql_amd.algo.pql_v_learner import LOSS_RING, LaggedLoss, _AdamState, _cfg_get, apply_optimizer, resident_norm
+from pql_amd.algo.pql_v_learner import LOSS_RING, LaggedLoss, allreduce_sum, _AdamState, _cfg_get, apply_optimizer, resident_norm
 from pql_amd.models import model_name_to_path
 from pql_amd.models.mlp import PackedWeights, default_splits, mlp_forward_raw, output_view
 from pql_amd.replay.simple_replay import RecordRing, _obs_width, ring_plan
@@ -67,6 +67,7 @@ class PQLPLearner:
         self.stream = torch.cuda.Stream(self.device) if bool(_cfg_get(algo, "streams", False)) else None
         self._ws = None
         self._graph = None
+        self._graph_post = None
         self._graph_key = None
 
     @property
@@ -109,7 +110,7 @@ class PQLPLearner:
         if self.pk_critic is not None:
             self.pk_critic.refresh(self.critic.arena.data)
 
-    def _step_kernels(self, ws, idx):
+    def _step_kernels(self, ws, idx, upto_backward=False):
         algo, dev, B = self.cfg.algo, self.device, ws["B"]
         O, A = self.ring.O, self.action_dim
         st = L.stream(dev)
@@ -137,16 +138,25 @@ class PQLPLearner:
         L.check(L.lib.pqlk_mlp_backward(C.byref(al.desc), L.ptr(self.actor.arena.data), L.ptr(ws["x_obs"]), ws["ld_o"], B,
                                         L.ptr(ws["acts_a"]), L.ptr(ws["dz_a"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0, 0,
                                         None, 0, L.ptr(ws["bwd_a"]), ws["bwd_a"].numel(), st))
+        if upto_backward:
+            return
+        self._allreduce_grads(ws)
+        self._step_post(ws)
+
+    def _allreduce_grads(self, ws):
         if self.world > 1:
-            torch.distributed.all_reduce(ws["grads"], group=self.pg)
+            allreduce_sum(ws["grads"], self.pg)
+
+    def _step_post(self, ws):
+        algo = self.cfg.algo
         apply_optimizer(self.actor.arena.data, ws["grads"], self.opt, None, algo.actor_lr, algo.max_grad_norm, 0.0,
-                        1.0 / self.world, dev)
+                        1.0 / self.world, self.device)
         if self.pk_actor is not None:
             self.pk_actor.refresh(self.actor.arena.data)
 
-    def _draw_and_step(self, ws):
+    def _draw_and_step(self, ws, upto_backward=False):
         ws["idx"].copy_(torch.randint(self.cur_capacity, size=(ws["B"],), device=self.device))  # the only draw (:49)
-        self._step_kernels(ws, ws["idx"])
+        self._step_kernels(ws, ws["idx"], upto_backward)
 
     @torch.no_grad()
     def learn(self, indices=None):
@@ -162,6 +172,9 @@ class PQLPLearner:
                 if self._graph is None or self._graph_key != key:
                     self._capture(ws, key)
                 self._graph.replay()
+                if self._graph_post is not None:
+                    self._allreduce_grads(ws)
+                    self._graph_post.replay()
             else:
                 self._draw_and_step(ws)
         self.update_count += 1
@@ -183,10 +196,18 @@ class PQLPLearner:
         self.repack()
         torch.cuda.set_rng_state(rng, self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._draw_and_step(ws)
+        g_post = None
+        if self.world == 1:
+            with torch.cuda.graph(g):
+                self._draw_and_step(ws)
+        else:
+            with torch.cuda.graph(g):
+                self._draw_and_step(ws, upto_backward=True)
+            g_post = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_post):
+                self._step_post(ws)
         torch.cuda.set_rng_state(rng, self.device)
-        self._graph, self._graph_key = g, key
+        self._graph, self._graph_post, self._graph_key = g, g_post, key
 
     def loss_mean(self):
         """Exact mean of the last 5 losses (Tracker(5).mean(), zero-filled before 5 steps); synchronises."""

@@ -58,6 +58,17 @@ def apply_optimizer(arena, grads, st: _AdamState, target, lr, max_grad_norm, tau
                                          L.ptr(st.scratch), L.stream(device)))
 
 
+def allreduce_sum(t, pg):
+    """Sum-all-reduce of the flat gradient arena.  RCCL ("nccl") reduces in place on the device over xGMI; the
+    gloo rehearsal path (CPU tests / one-GPU dry runs) stages through host memory."""
+    if torch.distributed.get_backend(pg) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        torch.distributed.all_reduce(h, group=pg)
+        t.copy_(h)
+    else:
+        torch.distributed.all_reduce(t, group=pg)
+
+
 class LaggedLoss:
     """Mean of the last LOSS_RING losses without stalling the stream: each call enqueues an async copy of the
     device ring to pinned host memory and returns the value of the last copy that has completed (one hand-off
@@ -151,6 +162,7 @@ class PQLVLearner:
         self.stream = torch.cuda.Stream(self.device) if bool(_cfg_get(algo, "streams", False)) else None
         self._ws = None
         self._graph = None
+        self._graph_post = None
         self._graph_key = None
 
     # ------------------------------------------------------------------------------------------
@@ -200,8 +212,9 @@ class PQLVLearner:
         mean, var, eps = self.normalize_tuple
         return mean, var, float(eps)
 
-    def _step_kernels(self, ws, idx, draw):
-        """The launch sequence of one critic gradient step; everything asynchronous on the current stream."""
+    def _step_kernels(self, ws, idx, draw, upto_backward=False):
+        """The launch sequence of one critic gradient step; everything asynchronous on the current stream.
+        upto_backward=True stops after the gradient is formed (graph capture around the DP all-reduce)."""
         algo, dev, B = self.cfg.algo, self.device, ws["B"]
         O = self.memory.ring.O
         st = L.stream(dev)
@@ -234,21 +247,30 @@ class PQLVLearner:
         L.check(L.lib.pqlk_mlp_backward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
                                         L.ptr(ws["acts_c"]), L.ptr(ws["dy"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0, 0,
                                         None, 0, L.ptr(ws["bwd"]), ws["bwd"].numel(), st))
-        if self.world > 1:  # data-parallel: sum over ranks on RCCL, mean folded into the optimiser's grad_scale
-            torch.distributed.all_reduce(ws["grads"], group=self.pg)
+        if upto_backward:
+            return
+        self._allreduce_grads(ws)
+        self._step_post(ws)
+
+    def _allreduce_grads(self, ws):
+        if self.world > 1:  # data-parallel: ONE collective per step, sum over ranks on RCCL; the mean is folded into
+            allreduce_sum(ws["grads"], self.pg)                         # the optimiser's grad_scale
+
+    def _step_post(self, ws):
+        algo, dev = self.cfg.algo, self.device
         apply_optimizer(self.critic.arena.data, ws["grads"], self.opt, self.critic_target.arena.data, algo.critic_lr,
                         algo.max_grad_norm, algo.tau, 1.0 / self.world, dev)
         if self._fused:   # fragment-ordered copies follow the new weights
             self.pk_critic.refresh(self.critic.arena.data)
             self.pk_target.refresh(self.critic_target.arena.data)
 
-    def _draw_and_step(self, ws):
+    def _draw_and_step(self, ws, upto_backward=False):
         B = ws["B"]
         # RNG consumption order of the reference: one randint(cur_capacity,(B,)) then one
         # N(0,1) draw of shape (B, A) on the learner's device generator.
         ws["idx"].copy_(torch.randint(self.memory.cur_capacity, size=(B,), device=self.device))
         ws["draw"].normal_()
-        self._step_kernels(ws, ws["idx"], ws["draw"])
+        self._step_kernels(ws, ws["idx"], ws["draw"], upto_backward)
 
     @torch.no_grad()
     def learn(self, indices=None, noise=None):
@@ -270,6 +292,9 @@ class PQLVLearner:
                 if self._graph is None or self._graph_key != key:
                     self._capture(ws, key)
                 self._graph.replay()
+                if self._graph_post is not None:   # data parallel: the collective stays outside the graphs
+                    self._allreduce_grads(ws)
+                    self._graph_post.replay()
             else:
                 self._draw_and_step(ws)
         self.update_count += 1
@@ -287,10 +312,18 @@ class PQLVLearner:
         torch.cuda.current_stream(self.device).wait_stream(s)
         self._restore(snap)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._draw_and_step(ws)
+        g_post = None
+        if self.world == 1:
+            with torch.cuda.graph(g):
+                self._draw_and_step(ws)
+        else:   # two graphs around the RCCL all-reduce (kept eager: no collective is ever captured)
+            with torch.cuda.graph(g):
+                self._draw_and_step(ws, upto_backward=True)
+            g_post = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_post):
+                self._step_post(ws)
         self._restore(snap)  # capture does not execute, but keep state exactly as before
-        self._graph, self._graph_key = g, key
+        self._graph, self._graph_post, self._graph_key = g, g_post, key
 
     def _snapshot(self):
         return [t.clone() for t in (self.critic.arena.data, self.critic_target.arena.data, self.opt.m, self.opt.v,

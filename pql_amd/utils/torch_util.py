@@ -57,8 +57,14 @@ class RunningMeanStd:
             return
         world = torch.distributed.get_world_size(pg)
         packed = torch.cat([bm.reshape(-1), bv.reshape(-1)])
-        gathered = torch.empty(world * packed.numel(), dtype=packed.dtype, device=packed.device)
-        torch.distributed.all_gather_into_tensor(gathered, packed, group=pg)
+        if torch.distributed.get_backend(pg) == "gloo" and packed.is_cuda:   # rehearsal path: stage through the host
+            hp = packed.cpu()
+            hg = torch.empty(world * hp.numel(), dtype=hp.dtype)
+            torch.distributed.all_gather_into_tensor(hg, hp, group=pg)
+            gathered = hg.to(packed.device)
+        else:
+            gathered = torch.empty(world * packed.numel(), dtype=packed.dtype, device=packed.device)
+            torch.distributed.all_gather_into_tensor(gathered, packed, group=pg)
         gathered = gathered.view(world, 2, -1)
         for r in range(world):
             self.update_from_moments(gathered[r, 0].view(self.mean.shape), gathered[r, 1].view(self.mean.shape), n)

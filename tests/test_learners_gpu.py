@@ -240,3 +240,56 @@ def test_train_pql_entry_point(dev, distl):
     out = mod.main(cfg)
     iters = (out["global_steps"] - 64 * 32) // 64
     assert out["critic_updates"] == 8 * iters and out["actor_updates"] == 4 * iters
+
+
+# --------------------------------------------------------------------------- data parallel on the GPU (2 ranks, one card)
+def _dp_rank(rank, world, port, ret):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # rehearsal backend; production uses RCCL ("nccl")
+    try:
+        from pql_amd.algo.pql_v_learner import PQLVLearner
+        from pql_amd.models.mlp import TanhMLPPolicy
+        dev = torch.device("cuda:0")
+        O, A, B = 8, 2, 64
+        g = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "learners.npz")))
+        outs = {}
+        for graph in (False, True):
+            v = PQLVLearner((O,), A, make_cfg(False, B=B // world, graph=graph), process_group=dist.group.WORLD)
+            v.critic.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 21))); v.critic_target.arena.data.copy_(v.critic.arena.data)
+            actor = TanhMLPPolicy((O,), A).to(dev); actor.load_state_dict(_sd(dd.mlp_state(O, A, 11)))
+            norm = (T(g["learner_norm_mean"]).to(dev), T(g["learner_norm_var"]).to(dev), 1e-4)
+            v.update(actor, tuple(t.to(dev) for t in _fill(O, A, 300, 810)), norm, 0)
+            if not graph:   # rank r takes idx[r*B/G:(r+1)*B/G] of the golden single-GPU batch (SURVEY 8e parity rule)
+                sl = slice(rank * B // world, (rank + 1) * B // world)
+                v.learn(indices=T(g["v_idx"][0][sl]), noise=T(g["v_noise"][0][sl]))
+                outs["injected"] = dd.summarize(v.critic.layout.weight(v.critic.arena.data, 0, 1).cpu().numpy())
+            else:           # graph mode: two captured graphs around the eager all-reduce; replicas must stay identical
+                torch.manual_seed(99)
+                for _ in range(3):
+                    v.learn()
+                torch.cuda.synchronize()
+                outs["graph"] = v.critic.arena.data.cpu().numpy()
+                outs["steps"] = v.opt.step.item()
+        ret[rank] = outs
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_match_single_gpu_step(golden, dev):
+    """Two ranks share the one GPU of the test box (gloo rehearsal backend): sharded batch + all-reduce + replicated
+    optimiser reproduces the golden single-GPU step, and the graph-captured DP step keeps the replicas bit-identical."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_dp_rank, args=(2, port, ret), nprocs=2, join=True)
+    g = golden("learners")
+    for r in (0, 1):
+        np.testing.assert_allclose(ret[r]["injected"], g["v_s0_p_net_q1.net.2.weight"], rtol=5e-5, atol=5e-7)
+        assert ret[r]["steps"] == 3
+    # different seeds-per-rank draws differ, but parameters are replicated: identical after the all-reduced steps
+    assert np.array_equal(ret[0]["graph"], ret[1]["graph"])
