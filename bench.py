@@ -343,7 +343,8 @@ def main():
         "value": value, "unit": "V-learner grad-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"PQL 1xMI355X cfg#2: {args.num_envs} synthetic envs ({args.task}-shape obs={O} act={A}), replay "
+        "config": {"workload": f"PQL {world}xMI355X cfg#2{' per rank (data parallel, RCCL grad all-reduce)' if world > 1 else ''}: "
+                               f"{args.num_envs} synthetic envs ({args.task}-shape obs={O} act={A}), replay "
                                f"{args.replay} rows resident in HBM, batch {args.batch}, n-step {args.nstep}, "
                                f"{'DistributionalDoubleQ(51)' if args.distl else 'DoubleQ'} MLP {hidden}",
                    "schedule": "v_only" if args.v_only else "1 env-iteration : 4 P-steps : 8 V-steps",
