@@ -241,6 +241,14 @@ int pqlk_clip_adamw_polyak(float* p, float* g, float* m, float* v, float* target
                            float max_norm, float lr, float b1, float b2, float eps, float wd, float tau,
                            int32_t* step_dev, float* gnorm_out, float* scratch, pqlk_stream_t stream);
 
+/* Same update for the arena of the MLP `d`, which ALSO refreshes the fragment-ordered weight copies of the fused
+ * forward path while each new value is in a register (packed_p for the parameters, packed_t -- may be NULL -- for the
+ * Polyak target), replacing the separate pqlk_mlp_pack launches. */
+int pqlk_clip_adamw_polyak_pack(const PqlMlpDesc* d, float* p, float* g, float* m, float* v, float* target,
+                                float* packed_p, float* packed_t, float grad_scale, float max_norm, float lr, float b1,
+                                float b2, float eps, float wd, float tau, int32_t* step_dev, float* gnorm_out,
+                                float* scratch, pqlk_stream_t stream);
+
 /* soft_update alone (torch_util.py:9-12): target = cur*tau + target*(1-tau). */
 int pqlk_polyak(float* target, const float* cur, int64_t n, float tau, pqlk_stream_t stream);
 

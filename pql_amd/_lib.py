@@ -56,6 +56,7 @@ PROTOTYPES = {
     "pqlk_c51_project": (C.c_int, [_P, _P, _P, _P, _F, _F, _F, _I32, _I64, _P, _P]),
     "pqlk_dpg_loss": (C.c_int, [_P, _I64, _I32, _P, _I64, _P, _P, _P, _I32, _P, _P]),
     "pqlk_clip_adamw_polyak": (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
+    "pqlk_clip_adamw_polyak_pack": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
     "pqlk_polyak": (C.c_int, [_P, _P, _I64, _F, _P]),
     "pqlk_batch_moments": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P, _P]),
 }

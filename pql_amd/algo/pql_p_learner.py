@@ -150,9 +150,7 @@ class PQLPLearner:
     def _step_post(self, ws):
         algo = self.cfg.algo
         apply_optimizer(self.actor.arena.data, ws["grads"], self.opt, None, algo.actor_lr, algo.max_grad_norm, 0.0,
-                        1.0 / self.world, self.device)
-        if self.pk_actor is not None:
-            self.pk_actor.refresh(self.actor.arena.data)
+                        1.0 / self.world, self.device, layout=self.actor.layout, packed=self.pk_actor)
 
     def _draw_and_step(self, ws, upto_backward=False):
         ws["idx"].copy_(torch.randint(self.cur_capacity, size=(ws["B"],), device=self.device))  # the only draw (:49)

@@ -49,8 +49,19 @@ class _AdamState:
         self.scratch = torch.zeros(2048, dtype=torch.float32, device=arena.device)
 
 
-def apply_optimizer(arena, grads, st: _AdamState, target, lr, max_grad_norm, tau, grad_scale=1.0, device=None):
-    """clip_grad_norm_ + AdamW(torch defaults: betas .9/.999, eps 1e-8, wd 1e-2) + optional Polyak."""
+def apply_optimizer(arena, grads, st: _AdamState, target, lr, max_grad_norm, tau, grad_scale=1.0, device=None, layout=None,
+                    packed=None, packed_target=None):
+    """clip_grad_norm_ + AdamW(torch defaults: betas .9/.999, eps 1e-8, wd 1e-2) + optional Polyak.
+    With `layout` + `packed` (PackedWeights with a tensor) the same launch also refreshes the fragment-ordered weight
+    copies of the fused forward path."""
+    mn = float(max_grad_norm) if max_grad_norm is not None else 0.0
+    if layout is not None and packed is not None and packed.tensor is not None:
+        pt = packed_target.tensor if packed_target is not None else None
+        L.check(L.lib.pqlk_clip_adamw_polyak_pack(C.byref(layout.desc), L.ptr(arena), L.ptr(grads), L.ptr(st.m), L.ptr(st.v),
+                                                  L.ptr(target), L.ptr(packed.tensor), L.ptr(pt), float(grad_scale), mn, float(lr),
+                                                  0.9, 0.999, 1e-8, 1e-2, float(tau), L.ptr(st.step), L.ptr(st.gnorm),
+                                                  L.ptr(st.scratch), L.stream(device)))
+        return
     L.check(L.lib.pqlk_clip_adamw_polyak(L.ptr(arena), L.ptr(grads), L.ptr(st.m), L.ptr(st.v), L.ptr(target),
                                          arena.numel(), float(grad_scale),
                                          float(max_grad_norm) if max_grad_norm is not None else 0.0,
@@ -258,11 +269,10 @@ class PQLVLearner:
 
     def _step_post(self, ws):
         algo, dev = self.cfg.algo, self.device
+        # optimiser + Polyak + refresh of the fragment-ordered weight copies (critic and target) in one launch pair
         apply_optimizer(self.critic.arena.data, ws["grads"], self.opt, self.critic_target.arena.data, algo.critic_lr,
-                        algo.max_grad_norm, algo.tau, 1.0 / self.world, dev)
-        if self._fused:   # fragment-ordered copies follow the new weights
-            self.pk_critic.refresh(self.critic.arena.data)
-            self.pk_target.refresh(self.critic_target.arena.data)
+                        algo.max_grad_norm, algo.tau, 1.0 / self.world, dev, layout=self.critic.layout,
+                        packed=self.pk_critic, packed_target=self.pk_target)
 
     def _draw_and_step(self, ws, upto_backward=False):
         B = ws["B"]

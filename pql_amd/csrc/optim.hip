@@ -29,6 +29,33 @@ __global__ __launch_bounds__(256) void k_sumsq(const float* __restrict__ g, int6
   }
 }
 
+// Optional fused re-pack: while the optimiser has each new weight (and Polyak target) in a register it also writes
+// it to the fragment-ordered copy used by the fused forward kernel (layout: fused.h), so no separate pack launches.
+#define PACK_MAX 16
+struct PackSpec {
+  int n;                      // number of (net, hidden layer) weight blocks; 0 = no packing
+  long long w_off[PACK_MAX];  // arena offset of the block
+  long long w_end[PACK_MAX];  // w_off + N * K
+  long long p_off[PACK_MAX];  // offset of the block in the packed buffer
+  int K[PACK_MAX];            // padded in-features (row length of the block)
+  float* packed_p;
+  float* packed_t;
+};
+
+__device__ __forceinline__ long long packed_index(const PackSpec& ps, long long i) {
+#pragma unroll 1
+  for (int e = 0; e < ps.n; ++e) {
+    if (i >= ps.w_off[e] && i < ps.w_end[e]) {
+      const long long rel = i - ps.w_off[e];
+      const int K = ps.K[e];
+      const int n = (int)(rel / K), k = (int)(rel - (long long)n * K);
+      const int tile = n >> 5, r = n & 31, k8 = k >> 3, h = (k >> 2) & 1, j = k & 3;
+      return ps.p_off[e] + (((long long)tile * (K >> 3) + k8) * 64 + h * 32 + r) * 4 + j;
+    }
+  }
+  return -1;
+}
+
 struct AdamC {
   float lr_wd_decay;  // 1 - lr*wd
   float w1;           // 1 - b1      (lerp weight)
@@ -41,7 +68,8 @@ struct AdamC {
 __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, float* __restrict__ target, int64_t n,
                                                const float* __restrict__ part, int nparts, AdamC c,
-                                               const int32_t* __restrict__ step_dev, float* __restrict__ gnorm_out) {
+                                               const int32_t* __restrict__ step_dev, float* __restrict__ gnorm_out,
+                                               PackSpec ps) {
   __shared__ float sh[256];
   __shared__ float s_coef, s_step_size, s_bc2_sqrt;
   // every block re-reduces the (<= 1024) partials in the same fixed order -> identical clip factor
@@ -78,14 +106,24 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
     p[i] = pi;
     m[i] = mi;
     v[i] = vi;
-    if (target) target[i] = pi * c.tau + target[i] * c.one_m_tau;  // soft_update
+    float ti = 0.f;
+    if (target) {
+      ti = pi * c.tau + target[i] * c.one_m_tau;  // soft_update
+      target[i] = ti;
+    }
+    if (ps.n > 0) {
+      const long long q = packed_index(ps, i);
+      if (q >= 0) {
+        ps.packed_p[q] = pi;
+        if (target && ps.packed_t) ps.packed_t[q] = ti;
+      }
+    }
   }
 }
 
-extern "C" int pqlk_clip_adamw_polyak(float* p, float* g, float* m, float* v, float* target, int64_t n, float grad_scale,
-                                      float max_norm,
-                                      float lr, float b1, float b2, float eps, float wd, float tau, int32_t* step_dev,
-                                      float* gnorm_out, float* scratch, pqlk_stream_t stream) {
+static int adamw_impl(float* p, float* g, float* m, float* v, float* target, int64_t n, float grad_scale, float max_norm, float lr,
+                      float b1, float b2, float eps, float wd, float tau, int32_t* step_dev, float* gnorm_out, float* scratch,
+                      const PackSpec& ps, pqlk_stream_t stream) {
   PQLK_REQUIRE(p && g && m && v && step_dev && scratch, PQLK_E_NULL);
   PQLK_REQUIRE(n > 0, PQLK_E_SHAPE);
   PQLK_REQUIRE(pqlk_aligned16(g), PQLK_E_ALIGN);
@@ -110,10 +148,50 @@ extern "C" int pqlk_clip_adamw_polyak(float* p, float* g, float* m, float* v, fl
   c.b2d = (double)b2;
   int blocks2 = (int)((n + 255) / 256);
   if (blocks2 > 2048) blocks2 = 2048;
-  hipLaunchKernelGGL(k_adamw, dim3(blocks2), dim3(256), 0, pqlk_s(stream), p, g, m, v, target, n, scratch, blocks, c,
-                     step_dev, gnorm_out);
+  hipLaunchKernelGGL(k_adamw, dim3(blocks2), dim3(256), 0, pqlk_s(stream), p, g, m, v, target, n, scratch, blocks, c, step_dev,
+                     gnorm_out, ps);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
+}
+
+extern "C" int pqlk_clip_adamw_polyak(float* p, float* g, float* m, float* v, float* target, int64_t n, float grad_scale,
+                                      float max_norm, float lr, float b1, float b2, float eps, float wd, float tau,
+                                      int32_t* step_dev, float* gnorm_out, float* scratch, pqlk_stream_t stream) {
+  PackSpec ps = {};
+  return adamw_impl(p, g, m, v, target, n, grad_scale, max_norm, lr, b1, b2, eps, wd, tau, step_dev, gnorm_out, scratch, ps, stream);
+}
+
+// Same, for the arena of an MLP described by `d`, also refreshing the fragment-ordered copies of the hidden-layer
+// weights (pqlk_mlp_pack layout): packed_p for the parameters, packed_t (may be NULL) for the Polyak target.
+extern "C" int pqlk_clip_adamw_polyak_pack(const PqlMlpDesc* d, float* p, float* g, float* m, float* v, float* target,
+                                           float* packed_p, float* packed_t, float grad_scale, float max_norm, float lr, float b1,
+                                           float b2, float eps, float wd, float tau, int32_t* step_dev, float* gnorm_out,
+                                           float* scratch, pqlk_stream_t stream) {
+  PQLK_REQUIRE(d && packed_p, PQLK_E_NULL);
+  PQLK_REQUIRE(d->n_layers >= 2 && d->n_layers <= PQLK_MAX_LAYERS && d->n_nets >= 1 && d->n_nets <= 2, PQLK_E_SHAPE);
+  PQLK_REQUIRE((d->n_layers - 1) * d->n_nets <= PACK_MAX, PQLK_E_UNSUPPORTED);
+  PQLK_REQUIRE(pqlk_mlp_packed_floats(d) > 0, PQLK_E_UNSUPPORTED);
+  const int64_t net_stride = pqlk_mlp_net_stride(d);
+  const int64_t packed_stride = pqlk_mlp_packed_floats(d) / d->n_nets;
+  PackSpec ps = {};
+  ps.packed_p = packed_p;
+  ps.packed_t = packed_t;
+  for (int net = 0; net < d->n_nets; ++net) {
+    int64_t p_off = 0;
+    for (int l = 0; l + 1 < d->n_layers; ++l) {
+      int64_t w_off, b_off;
+      pqlk_mlp_layer_offsets(d, l, &w_off, &b_off);
+      const int64_t K = pqlk_ld(d->dims[l]), N = d->dims[l + 1];
+      const int e = ps.n++;
+      ps.w_off[e] = net * net_stride + w_off;
+      ps.w_end[e] = ps.w_off[e] + N * K;
+      ps.p_off[e] = net * packed_stride + p_off;
+      ps.K[e] = (int)K;
+      p_off += N * K;
+    }
+  }
+  return adamw_impl(p, g, m, v, target, pqlk_mlp_param_floats(d), grad_scale, max_norm, lr, b1, b2, eps, wd, tau, step_dev,
+                    gnorm_out, scratch, ps, stream);
 }
 
 __global__ __launch_bounds__(256) void k_polyak(float* __restrict__ target, const float* __restrict__ cur, int64_t n,

@@ -442,3 +442,32 @@ def test_fused_path_is_declined_for_unsupported_widths(dev):
     assert PackedWeights(ArenaLayout([8, 100, 64, 1], 1), dev).tensor is None      # hidden width not a multiple of 32
     assert PackedWeights(ArenaLayout([8, 1024, 1024, 1], 1), dev).tensor is None   # two LDS activation buffers > 160 KB
     assert PackedWeights(ArenaLayout([8, 1], 1), dev).tensor is None               # no hidden layer
+
+
+def test_optimizer_refreshes_packed_weight_copies(dev):
+    """pqlk_clip_adamw_polyak_pack must leave packed_p == pack(new params) and packed_t == pack(new target), and the
+    same parameters as the plain optimiser entry point."""
+    from pql_amd import _lib as L
+    from pql_amd.models.mlp import ArenaLayout, PackedWeights
+    lay = ArenaLayout([104, 512, 256, 128, 1], 2)
+    n = lay.total
+    p0 = T(dd.uniform((n,), 1, -0.1, 0.1)).to(dev); t0 = T(dd.uniform((n,), 2, -0.1, 0.1)).to(dev)
+    g = T(dd.uniform((n,), 3, -1, 1)).to(dev)
+    outs = []
+    for packing in (False, True):
+        p, tg = p0.clone(), t0.clone()
+        m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+        step = torch.zeros(1, dtype=torch.int32, device=dev); scr = torch.zeros(2048, device=dev)
+        pk_p, pk_t = PackedWeights(lay, dev), PackedWeights(lay, dev)
+        if packing:
+            L.check(L.lib.pqlk_clip_adamw_polyak_pack(C.byref(lay.desc), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(tg),
+                                                      L.ptr(pk_p.tensor), L.ptr(pk_t.tensor), 1.0, 0.5, 5e-4, 0.9, 0.999, 1e-8, 1e-2,
+                                                      0.05, L.ptr(step), None, L.ptr(scr), L.stream(dev)))
+            ref_p, ref_t = PackedWeights(lay, dev).refresh(p).tensor, PackedWeights(lay, dev).refresh(tg).tensor
+            assert torch.equal(pk_p.tensor, ref_p) and torch.equal(pk_t.tensor, ref_t)
+        else:
+            L.check(L.lib.pqlk_clip_adamw_polyak(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), L.ptr(tg), n, 1.0, 0.5, 5e-4, 0.9, 0.999,
+                                                 1e-8, 1e-2, 0.05, L.ptr(step), None, L.ptr(scr), L.stream(dev)))
+        outs.append((p, tg, m, v))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
