@@ -37,14 +37,14 @@ __device__ __forceinline__ float fused_elu(float x) { return x > 0.f ? x : __exp
 // wait degrades to `vmcnt(0) lgkmcnt(0)`, which drains the weight prefetch ring on each k-step.
 extern __shared__ __attribute__((aligned(16))) float fsm[];
 
-template <int TPW>
+template <int TPW, int NW>
 __device__ __forceinline__ void fused_layer(int in_off, int out_off, int buf_ld, int K,
                                             int N, const float* __restrict__ packed_l, const float* __restrict__ bias_l,
                                             float* __restrict__ gout, int g_ld, int row0, int B, int wave, int lane) {
   const int r = lane & 31, h = lane >> 5;
   const int K8 = K >> 3;
   const int ntiles = N >> 5;
-  for (int tbase = wave * TPW; tbase < ntiles; tbase += 4 * TPW) {
+  for (int tbase = wave * TPW; tbase < ntiles; tbase += NW * TPW) {
     f32x16f acc[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; ++j)
@@ -98,7 +98,11 @@ __device__ __forceinline__ void fused_layer(int in_off, int out_off, int buf_ld,
   }
 }
 
-__global__ __launch_bounds__(256) void k_mlp_fwd_fused(FusedP p) {
+#ifndef PQLK_FUSED_WAVES
+#define PQLK_FUSED_WAVES 8   // waves per block: 8 = two per SIMD, so one wave's LDS / L2 waits hide behind the other's MFMAs
+#endif
+__global__ __launch_bounds__(64 * PQLK_FUSED_WAVES) void k_mlp_fwd_fused(FusedP p) {
+  constexpr int NW = PQLK_FUSED_WAVES;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware block -> (net, row tile) map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share
   // an L2), and a twin critic's fragment-ordered weights are 2 x 1.8 MB against a 4 MB L2: with both nets on every
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_fused(FusedP p) {
   {  // stage the input tile (pad columns of X are zero by contract; rows past B are zero-filled)
     const int k0 = (p.dims[0] + 31) & ~31;
     const int cpr = k0 >> 2;
-    for (int i = tid; i < 32 * cpr; i += 256) {
+    for (int i = tid; i < 32 * cpr; i += 64 * NW) {
       const int row = i / cpr, c4 = i % cpr;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row0 + row < p.B) v = *reinterpret_cast<const float4*>(p.X + (long long)(row0 + row) * p.ldx + 4 * c4);
@@ -134,9 +138,9 @@ __global__ __launch_bounds__(256) void k_mlp_fwd_fused(FusedP p) {
     float* gout = (p.stash_all || l == p.n_hidden - 1) ? p.acts + p.a_off[l] + (long long)net * p.B * N : nullptr;
     const int ntiles = N >> 5;
     const int in = boff[l & 1], out = boff[(l & 1) ^ 1];
-    if ((ntiles & 15) == 0) fused_layer<4>(in, out, p.buf_ld, K, N, packed_l, bias_l, gout, N, row0, p.B, wave, lane);
-    else if ((ntiles & 7) == 0) fused_layer<2>(in, out, p.buf_ld, K, N, packed_l, bias_l, gout, N, row0, p.B, wave, lane);
-    else fused_layer<1>(in, out, p.buf_ld, K, N, packed_l, bias_l, gout, N, row0, p.B, wave, lane);
+    if (ntiles % (4 * NW) == 0) fused_layer<4, NW>(in, out, p.buf_ld, K, N, packed_l, bias_l, gout, N, row0, p.B, wave, lane);
+    else if (ntiles % (2 * NW) == 0) fused_layer<2, NW>(in, out, p.buf_ld, K, N, packed_l, bias_l, gout, N, row0, p.B, wave, lane);
+    else fused_layer<1, NW>(in, out, p.buf_ld, K, N, packed_l, bias_l, gout, N, row0, p.B, wave, lane);
     __syncthreads();
   }
 }

@@ -569,7 +569,7 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
     if (e != hipSuccess) return -(int)e;
     attr_set = 160 * 1024;
   }
-  hipLaunchKernelGGL(k_mlp_fwd_fused, dim3((unsigned)(((b + 31) / 32) * d->n_nets)), dim3(256), shmem, st, p);
+  hipLaunchKernelGGL(k_mlp_fwd_fused, dim3((unsigned)(((b + 31) / 32) * d->n_nets)), dim3(64 * PQLK_FUSED_WAVES), shmem, st, p);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }

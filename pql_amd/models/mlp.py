@@ -76,7 +76,9 @@ class ArenaLayout:
 
 def default_splits(B: int) -> int:
     """Batch splits of the dW GEMM: enough (net x tile x split) blocks to cover 256 CUs, >= 256 rows each."""
-    return int(max(1, min(16, B // 512)))
+    import os
+    cap = int(os.environ.get("PQLK_SPLITS", 16))   # tuning override
+    return int(max(1, min(cap, B // 512)))
 
 
 def pad_cols(x: torch.Tensor, ld: int) -> torch.Tensor:
