@@ -354,18 +354,26 @@ def main():
         "gflop_per_v_step": f_v / 1e9, "gflop_per_p_step": f_p / 1e9,
     }
     if rank == 0:
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # from the committed rocprofv3 --pmc passes
+        if os.path.exists(tpath) and args.hidden == "512,512,256" and args.task == "AllegroHand" and args.batch == 8192:
+            traffic = json.load(open(tpath))
         # roofline of the dominant kernel family: the fp32-MFMA GEMMs of one V step (k_gemm<...>)
         ms = gemm_section_ms(v)
         achieved = f_v / (ms * 1e-3) / 1e12
         line["roofline"] = {"bound": "mfma", "kernel": "k_gemm + k_mlp_fwd_fused (all fp32 v_mfma_f32_32x32x2 launches of one V-learner step)",
                             "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "ms_per_launch_group": ms}
+                            "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("mfma_family_per_v_step_bytes"),
+                            "traffic_note": "bytes at the L2<->fabric boundary per V step (FETCH_SIZE x2 + WRITE_SIZE, PMC passes in "
+                                            "profiles/r01_pmc_traffic.json); the family is MFMA-bound, not HBM-bound",
+                            "ms_per_launch_group": ms}
         gms = gather_ms(v)
         rec_ld = v.memory.ring.rec_ld
         alg_bytes = args.batch * ((2 * O + A) * 4 + 4 + 1 + 8 + (2 * O + A) * 4 + 4 + 4)   # 1557 B/sample @cfg2
         line["roofline_gather"] = {"bound": "hbm", "kernel": "k_replay_gather_fused", "achieved": alg_bytes / (gms * 1e-3) / 1e9,
                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_bytes / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                   "traffic": None, "us_per_launch": gms * 1e3, "record_bytes": rec_ld * 4}
+                                   "traffic": traffic.get("gather_per_launch_bytes"), "algorithmic_bytes": alg_bytes,
+                                   "us_per_launch": gms * 1e3, "record_bytes": rec_ld * 4}
         note("roofline sections measured")
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, O, A, hidden)
