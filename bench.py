@@ -173,8 +173,9 @@ def gemm_section_ms(v, iters=20):
 
     def section():
         from pql_amd.models.mlp import mlp_forward_raw
-        mlp_forward_raw(al, v.actor.arena.data, ws["xn_obs"], L.ACT_TANH_NOISE, ws["draw"], 0.8, 0.2, ws["acts_a"], ws["xn_sa"][:, O:],
-                        packed=v.pk_actor, stash_all=False)
+        fused_actor = v.pk_actor is not None and v.pk_actor.tensor is not None
+        mlp_forward_raw(al, v.actor.arena.data, ws["xn_sa"] if fused_actor else ws["xn_obs"], L.ACT_TANH_NOISE, ws["draw"], 0.8, 0.2,
+                        ws["acts_a"], ws["xn_sa"][:, O:], packed=v.pk_actor, stash_all=False)
         mlp_forward_raw(cl, v.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"], packed=v.pk_target, stash_all=False)
         mlp_forward_raw(cl, v.critic.arena.data, ws["x_sa"], L.ACT_NONE, acts=ws["acts_c"], packed=v.pk_critic, stash_all=True)
         L.check(L.lib.pqlk_mlp_backward(C.byref(cl.desc), L.ptr(v.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
@@ -201,10 +202,12 @@ def gather_ms(v, iters=50):
     B = ws["B"]
     mean, var, eps = v._norm_ptrs()
     idx = torch.randint(v.memory.cur_capacity, size=(iters + 3, B), device=v.device)
+    fused_actor = v.pk_actor is not None and v.pk_actor.tensor is not None
 
     def one(i):
         L.check(L.lib.pqlk_replay_gather_fused(C.byref(v.memory.ring.desc), L.ptr(idx[i]), B, L.ptr(mean), L.ptr(var), eps, 1,
-                                               L.ptr(ws["x_sa"]), ws["ld_sa"], L.ptr(ws["xn_sa"]), L.ptr(ws["xn_obs"]), ws["ld_o"],
+                                               L.ptr(ws["x_sa"]), ws["ld_sa"], L.ptr(ws["xn_sa"]),
+                                               None if fused_actor else L.ptr(ws["xn_obs"]), ws["ld_o"],
                                                L.ptr(ws["rew"]), L.ptr(ws["done"]), L.stream(v.device)))
     with torch.cuda.device(v.device):
         for i in range(3):
@@ -343,7 +346,7 @@ def main():
         "value": value, "unit": "V-learner grad-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"PQL {world}xMI355X cfg#2{' per rank (data parallel, RCCL grad all-reduce)' if world > 1 else ''}: "
+        "config": {"workload": f"PQL {world}xMI355X{' per rank (data parallel, RCCL grad all-reduce)' if world > 1 else ''}: "
                                f"{args.num_envs} synthetic envs ({args.task}-shape obs={O} act={A}), replay "
                                f"{args.replay} rows resident in HBM, batch {args.batch}, n-step {args.nstep}, "
                                f"{'DistributionalDoubleQ(51)' if args.distl else 'DoubleQ'} MLP {hidden}",

@@ -172,7 +172,8 @@ int pqlk_mlp_pack(const PqlMlpDesc* d, const float* params, float* packed, pqlk_
  * packed != NULL (from pqlk_mlp_pack of the SAME params) selects the fused path: all hidden layers in one launch with
  * the activations of a 32-row tile resident in LDS; results are identical to the per-layer path (same accumulation
  * order).  stash_all = 0 on that path skips the HBM write of all but the last hidden layer (inference-only chains);
- * backward needs stash_all = 1. */
+ * backward needs stash_all = 1.  On the fused path columns [dims[0], ldx) of x are IGNORED (masked to zero while the
+ * tile is staged), so x may alias a wider matrix; the per-layer path requires them to be zero. */
 int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const float* packed, int32_t stash_all,
                      const float* x, int64_t ldx, int64_t b,
                      int32_t out_act, const float* draw, float noise_std, float noise_clip,

@@ -230,14 +230,18 @@ class PQLVLearner:
         O = self.memory.ring.O
         st = L.stream(dev)
         mean, var, eps = self._norm_ptrs()
+        # the fused actor forward masks everything past column O while staging its tile, so it can read norm(next_obs)
+        # straight out of the target critic's input tile: one gather output (B x ld(O) floats) less to write
+        actor_in_sa = self.pk_actor is not None and self.pk_actor.tensor is not None
         L.check(L.lib.pqlk_replay_gather_fused(C.byref(self.memory.ring.desc), L.ptr(idx), B, L.ptr(mean), L.ptr(var), eps, 1,
-                                               L.ptr(ws["x_sa"]), ws["ld_sa"], L.ptr(ws["xn_sa"]), L.ptr(ws["xn_obs"]),
+                                               L.ptr(ws["x_sa"]), ws["ld_sa"], L.ptr(ws["xn_sa"]),
+                                               None if actor_in_sa else L.ptr(ws["xn_obs"]),
                                                ws["ld_o"], L.ptr(ws["rew"]), L.ptr(ws["done"]), st))
         al, cl = self.actor.layout, self.critic.layout
         # target policy smoothing (:63-71): a' written into the action columns of the target critic's input.
         # The two no-grad chains (actor, target critic) skip the activation stash; the critic keeps it for backward.
         xn_act = ws["xn_sa"][:, O:]
-        mlp_forward_raw(al, self.actor.arena.data, ws["xn_obs"], L.ACT_TANH_NOISE, draw, algo.noise.tgt_pol_std,
+        mlp_forward_raw(al, self.actor.arena.data, ws["xn_sa"] if actor_in_sa else ws["xn_obs"], L.ACT_TANH_NOISE, draw, algo.noise.tgt_pol_std,
                         algo.noise.tgt_pol_noise_bound, ws["acts_a"], xn_act, packed=self.pk_actor, stash_all=False)
         mlp_forward_raw(cl, self.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"], packed=self.pk_target,
                         stash_all=False)

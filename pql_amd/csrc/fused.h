@@ -127,6 +127,15 @@ __global__ __launch_bounds__(64 * PQLK_FUSED_WAVES) void k_mlp_fwd_fused(FusedP 
       const int row = i / cpr, c4 = i % cpr;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row0 + row < p.B) v = *reinterpret_cast<const float4*>(p.X + (long long)(row0 + row) * p.ldx + 4 * c4);
+      // columns past the logical input width are forced to zero here, so X may be a wider matrix whose extra columns
+      // hold something else (the target actor reads its observations straight out of the critic's [obs | action] tile)
+      const int c = 4 * c4, w = p.dims[0];
+      if (c + 3 >= w) {
+        if (c >= w) v.x = 0.f;
+        if (c + 1 >= w) v.y = 0.f;
+        if (c + 2 >= w) v.z = 0.f;
+        v.w = 0.f;
+      }
       *reinterpret_cast<float4*>(&fsm[row * p.buf_ld + 4 * c4]) = v;
     }
   }

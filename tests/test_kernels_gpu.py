@@ -471,3 +471,24 @@ def test_optimizer_refreshes_packed_weight_copies(dev):
         outs.append((p, tg, m, v))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_fused_forward_ignores_columns_past_the_input_width(dev):
+    """The fused path masks x[:, dims[0]:] while staging, so the target actor can read norm(next_obs) out of the wider
+    [obs | action] tile whose extra columns are NOT zero."""
+    from pql_amd import _lib as L
+    from pql_amd.models.mlp import ArenaLayout, PackedWeights, mlp_forward_raw, output_view
+    dims, B = [88, 512, 256, 128, 16], 300
+    lay = ArenaLayout(dims, 1)
+    arena = torch.zeros(lay.total, device=dev)
+    for l in range(lay.n_layers):
+        bound = 1.0 / np.sqrt(dims[l])
+        lay.weight(arena, 0, l).copy_(T(dd.uniform((dims[l + 1], dims[l]), l, -bound, bound)))
+        lay.bias(arena, 0, l).copy_(T(dd.uniform((dims[l + 1],), l + 50, -bound, bound)))
+    pk = PackedWeights(lay, dev).refresh(arena)
+    obs = T(dd.uniform((B, 88), 7, -2, 2)).to(dev)
+    clean = torch.zeros((B, 96), device=dev); clean[:, :88] = obs
+    wide = torch.full((B, 128), 1e30, device=dev); wide[:, :88] = obs          # "action" columns hold garbage
+    y0 = output_view(lay, mlp_forward_raw(lay, arena, clean, L.ACT_TANH, packed=pk, stash_all=False), B).clone()
+    y1 = output_view(lay, mlp_forward_raw(lay, arena, wide, L.ACT_TANH, packed=pk, stash_all=False), B)
+    assert torch.equal(y0, y1) and torch.isfinite(y1).all()
