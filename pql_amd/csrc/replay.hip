@@ -127,6 +127,8 @@ __device__ __forceinline__ float norm1(float x, float mean, float sd, int clamp5
 }
 
 #define GATHER_MAX_OBS 1024
+#define O_PADS_FIT(L, ld_sa, ld_o, xn_obs) \
+  ((2 * (((ld_sa) - (L).O - (L).A) >> 2) + ((xn_obs) ? (((ld_o) - (L).O) >> 2) : 0)) <= 64)
 
 // store up to 4 consecutive columns [col, col+4) of a row, clipped to `limit` columns; one 16-B store when the
 // destination is 16-B aligned and unclipped, scalar stores otherwise
@@ -236,6 +238,90 @@ __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __rest
   }
 }
 
+// Fast path for the common aligned shape (O % 4 == 0, A % 4 == 0, record <= 64 chunks, transition ring): the field
+// decode, destination and normalisation constants of a lane depend only on its chunk index, so they are computed ONCE
+// per kernel and the per-row work is load -> (sub, IEEE div, clamp) x4 -> one or two 16-B stores.  The generic kernel
+// above re-decodes the field per row and is instruction-issue bound (~450 instructions per row).
+template <bool HAS_NORM, int R>
+__global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restrict__ records, RecLayout L, int64_t capacity,
+                                                            const int64_t* __restrict__ idx, int64_t b,
+                                                            const float* __restrict__ mean, const float* __restrict__ var,
+                                                            float eps, int clamp5, float* __restrict__ x_sa, int64_t ld_sa,
+                                                            float* __restrict__ xn_sa, float* __restrict__ xn_obs, int64_t ld_o,
+                                                            float* __restrict__ o_rew, float* __restrict__ o_done) {
+  const int lane = threadIdx.x & 63;
+  const int c = lane << 2;
+  const int nchunk = L.used >> 2;
+  // per-lane plan
+  float* dstA = nullptr;
+  float* dstB = nullptr;
+  int64_t ldA = 0, ldB = 0;
+  int ncol = -1;  // column of the normalisation constants, -1 = copy
+  bool is_rd = false;
+  if (lane < nchunk) {
+    if (c < L.o4) {
+      dstA = x_sa ? x_sa + c : nullptr; ldA = ld_sa; ncol = c;
+    } else if (c < L.off_act) {
+      const int cc = c - L.off_nobs;
+      dstA = xn_sa ? xn_sa + cc : nullptr; ldA = ld_sa;
+      dstB = xn_obs ? xn_obs + cc : nullptr; ldB = ld_o;
+      ncol = cc;
+    } else if (c < L.off_rd) {
+      dstA = x_sa ? x_sa + L.O + (c - L.off_act) : nullptr; ldA = ld_sa;
+    } else {
+      is_rd = true;
+    }
+  }
+  float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  const bool do_norm = HAS_NORM && ncol >= 0;
+  if (do_norm) {
+    m4 = *reinterpret_cast<const float4*>(mean + ncol);
+    const float4 v4 = *reinterpret_cast<const float4*>(var + ncol);
+    s4 = make_float4(sqrtf(v4.x + eps), sqrtf(v4.y + eps), sqrtf(v4.z + eps), sqrtf(v4.w + eps));
+  }
+  // pad columns [O+A, ld_sa) of x_sa / xn_sa and [O, ld_o) of xn_obs: lanes take one 16-B zero store each
+  const int sa_cols = L.O + L.A;
+  const int npad_sa = (int)(ld_sa - sa_cols) >> 2, npad_o = xn_obs ? (int)(ld_o - L.O) >> 2 : 0;
+  float* padp = nullptr;
+  int64_t padld = 0;
+  if (lane < npad_sa) { padp = x_sa ? x_sa + sa_cols + 4 * lane : nullptr; padld = ld_sa; }
+  else if (lane < 2 * npad_sa) { padp = xn_sa ? xn_sa + sa_cols + 4 * (lane - npad_sa) : nullptr; padld = ld_sa; }
+  else if (lane < 2 * npad_sa + npad_o) { padp = xn_obs + L.O + 4 * (lane - 2 * npad_sa); padld = ld_o; }
+
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t r0 = wave * R; r0 < b; r0 += nwaves * R) {
+    float4 v[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int64_t r = r0 + i;
+      int64_t src = r < b ? idx[r] : 0;
+      if (src < 0 || src >= capacity) src = 0;
+      v[i] = lane < nchunk ? reinterpret_cast<const float4*>(records + src * L.ld)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int64_t r = r0 + i;
+      if (r >= b) break;
+      float4 x = v[i];
+      if (do_norm) {
+        x.x = (x.x - m4.x) / s4.x; x.y = (x.y - m4.y) / s4.y; x.z = (x.z - m4.z) / s4.z; x.w = (x.w - m4.w) / s4.w;
+        if (clamp5) {
+          x.x = fminf(fmaxf(x.x, -5.f), 5.f); x.y = fminf(fmaxf(x.y, -5.f), 5.f);
+          x.z = fminf(fmaxf(x.z, -5.f), 5.f); x.w = fminf(fmaxf(x.w, -5.f), 5.f);
+        }
+      }
+      if (dstA) *reinterpret_cast<float4*>(dstA + r * ldA) = x;
+      if (dstB) *reinterpret_cast<float4*>(dstB + r * ldB) = x;
+      if (is_rd) {
+        if (o_rew) o_rew[r] = x.x;
+        if (o_done) o_done[r] = x.y;
+      }
+      if (padp) *reinterpret_cast<float4*>(padp + r * padld) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+
 template <bool HAS_NORM>
 static void launch_gather_fused(int nchunk, unsigned blocks, hipStream_t st, const float* records, RecLayout L, int64_t capacity,
                                 const int64_t* idx, int64_t b, const float* mean, const float* var, float eps, int clamp5,
@@ -269,6 +355,22 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
   const int rows_per_wave = nchunk <= 64 ? 4 : (nchunk <= 128 ? 2 : 1);
   int64_t blocks = (b + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
   if (blocks > 2048) blocks = 2048;
+  // aligned transition-ring shape -> lean kernel (pads: at most 64 16-B chunks in total, one lane each)
+  const bool fast = L.A >= 0 && (L.O & 3) == 0 && (L.A & 3) == 0 && nchunk <= 64 && O_PADS_FIT(L, ld_sa, ld_o, xn_obs) &&
+                    pqlk_aligned16(x_sa) && pqlk_aligned16(xn_sa) && pqlk_aligned16(xn_obs) &&
+                    (!mean || (pqlk_aligned16(mean) && pqlk_aligned16(var)));
+  if (fast) {
+    int64_t fb = (b + 15) / 16;
+    if (fb > 2048) fb = 2048;
+    if (mean)
+      hipLaunchKernelGGL((k_replay_gather_fast<true, 4>), dim3((unsigned)fb), dim3(256), 0, pqlk_s(stream), ring->records, L,
+                         ring->capacity, idx, b, mean, var, eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done);
+    else
+      hipLaunchKernelGGL((k_replay_gather_fast<false, 4>), dim3((unsigned)fb), dim3(256), 0, pqlk_s(stream), ring->records, L,
+                         ring->capacity, idx, b, mean, var, eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done);
+    PQLK_LAUNCH_CHECK();
+    return PQLK_OK;
+  }
   if (mean)
     launch_gather_fused<true>(nchunk, (unsigned)blocks, pqlk_s(stream), ring->records, L, ring->capacity, idx, b, mean, var, eps,
                               clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done);
