@@ -127,8 +127,6 @@ __device__ __forceinline__ float norm1(float x, float mean, float sd, int clamp5
 }
 
 #define GATHER_MAX_OBS 1024
-#define O_PADS_FIT(L, ld_sa, ld_o, xn_obs) \
-  ((2 * (((ld_sa) - (L).O - (L).A) >> 2) + ((xn_obs) ? (((ld_o) - (L).O) >> 2) : 0)) <= 64)
 
 // store up to 4 consecutive columns [col, col+4) of a row, clipped to `limit` columns; one 16-B store when the
 // destination is 16-B aligned and unclipped, scalar stores otherwise
@@ -238,7 +236,7 @@ __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __rest
   }
 }
 
-// Fast path for the common aligned shape (O % 4 == 0, A % 4 == 0, record <= 64 chunks, transition ring): the field
+// Fast path for transition rings whose record fits one 16-B chunk per lane (<= 1 KiB used, e.g. cfg #2 and #5): the field
 // decode, destination and normalisation constants of a lane depend only on its chunk index, so they are computed ONCE
 // per kernel and the per-row work is load -> (sub, IEEE div, clamp) x4 -> one or two 16-B stores.  The generic kernel
 // above re-decodes the field per row and is instruction-issue bound (~450 instructions per row).
@@ -256,37 +254,40 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
   float* dstA = nullptr;
   float* dstB = nullptr;
   int64_t ldA = 0, ldB = 0;
-  int ncol = -1;  // column of the normalisation constants, -1 = copy
-  bool is_rd = false;
+  int ncol = -1;    // column of the normalisation constants, -1 = copy
+  int nvalid = 4;   // logical elements in this chunk (< 4 only in a field's last chunk when O or A is not a multiple of 4)
+  bool vecA = true, is_rd = false;
   if (lane < nchunk) {
     if (c < L.o4) {
-      dstA = x_sa ? x_sa + c : nullptr; ldA = ld_sa; ncol = c;
+      dstA = x_sa ? x_sa + c : nullptr; ldA = ld_sa; ncol = c; nvalid = min(4, L.O - c);
     } else if (c < L.off_act) {
       const int cc = c - L.off_nobs;
       dstA = xn_sa ? xn_sa + cc : nullptr; ldA = ld_sa;
       dstB = xn_obs ? xn_obs + cc : nullptr; ldB = ld_o;
-      ncol = cc;
+      ncol = cc; nvalid = min(4, L.O - cc);
     } else if (c < L.off_rd) {
-      dstA = x_sa ? x_sa + L.O + (c - L.off_act) : nullptr; ldA = ld_sa;
+      const int cc = c - L.off_act;
+      dstA = x_sa ? x_sa + L.O + cc : nullptr; ldA = ld_sa; nvalid = min(4, L.A - cc);
+      vecA = (L.O & 3) == 0;   // action columns start at O: 16-B aligned only then
     } else {
       is_rd = true;
     }
   }
+  vecA = vecA && nvalid == 4;
   float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
   const bool do_norm = HAS_NORM && ncol >= 0;
-  if (do_norm) {
-    m4 = *reinterpret_cast<const float4*>(mean + ncol);
-    const float4 v4 = *reinterpret_cast<const float4*>(var + ncol);
-    s4 = make_float4(sqrtf(v4.x + eps), sqrtf(v4.y + eps), sqrtf(v4.z + eps), sqrtf(v4.w + eps));
+  if (do_norm) {   // scalar loads: O need not be a multiple of 4; invalid tail elements keep (0, 1)
+    float mm[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nvalid) { mm[j] = mean[ncol + j]; ss[j] = sqrtf(var[ncol + j] + eps); }
+    m4 = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    s4 = make_float4(ss[0], ss[1], ss[2], ss[3]);
   }
   // pad columns [O+A, ld_sa) of x_sa / xn_sa and [O, ld_o) of xn_obs: lanes take one 16-B zero store each
+  // (scalar, <= 31 per matrix: ld - cols < 32 + 3; pads are a few dozen bytes per row)
   const int sa_cols = L.O + L.A;
-  const int npad_sa = (int)(ld_sa - sa_cols) >> 2, npad_o = xn_obs ? (int)(ld_o - L.O) >> 2 : 0;
-  float* padp = nullptr;
-  int64_t padld = 0;
-  if (lane < npad_sa) { padp = x_sa ? x_sa + sa_cols + 4 * lane : nullptr; padld = ld_sa; }
-  else if (lane < 2 * npad_sa) { padp = xn_sa ? xn_sa + sa_cols + 4 * (lane - npad_sa) : nullptr; padld = ld_sa; }
-  else if (lane < 2 * npad_sa + npad_o) { padp = xn_obs + L.O + 4 * (lane - 2 * npad_sa); padld = ld_o; }
+  const int npad_sa = (int)(ld_sa - sa_cols), npad_o = xn_obs ? (int)(ld_o - L.O) : 0;
 
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -311,13 +312,32 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
           x.z = fminf(fmaxf(x.z, -5.f), 5.f); x.w = fminf(fmaxf(x.w, -5.f), 5.f);
         }
       }
-      if (dstA) *reinterpret_cast<float4*>(dstA + r * ldA) = x;
-      if (dstB) *reinterpret_cast<float4*>(dstB + r * ldB) = x;
+      const float e[4] = {x.x, x.y, x.z, x.w};
+      if (dstA) {
+        if (vecA) *reinterpret_cast<float4*>(dstA + r * ldA) = x;
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < nvalid) dstA[r * ldA + j] = e[j];
+        }
+      }
+      if (dstB) {
+        if (nvalid == 4) *reinterpret_cast<float4*>(dstB + r * ldB) = x;
+        else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < nvalid) dstB[r * ldB + j] = e[j];
+        }
+      }
       if (is_rd) {
         if (o_rew) o_rew[r] = x.x;
         if (o_done) o_done[r] = x.y;
       }
-      if (padp) *reinterpret_cast<float4*>(padp + r * padld) = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < npad_sa) {
+        if (x_sa) x_sa[r * ld_sa + sa_cols + lane] = 0.f;
+        if (xn_sa) xn_sa[r * ld_sa + sa_cols + lane] = 0.f;
+      }
+      if (lane < npad_o) xn_obs[r * ld_o + L.O + lane] = 0.f;
     }
   }
 }
@@ -356,9 +376,8 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
   int64_t blocks = (b + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
   if (blocks > 2048) blocks = 2048;
   // aligned transition-ring shape -> lean kernel (pads: at most 64 16-B chunks in total, one lane each)
-  const bool fast = L.A >= 0 && (L.O & 3) == 0 && (L.A & 3) == 0 && nchunk <= 64 && O_PADS_FIT(L, ld_sa, ld_o, xn_obs) &&
-                    pqlk_aligned16(x_sa) && pqlk_aligned16(xn_sa) && pqlk_aligned16(xn_obs) &&
-                    (!mean || (pqlk_aligned16(mean) && pqlk_aligned16(var)));
+  const bool fast = L.A >= 0 && nchunk <= 64 && (ld_sa - L.O - L.A) <= 64 && (!xn_obs || (ld_o - L.O) <= 64) &&
+                    pqlk_aligned16(x_sa) && pqlk_aligned16(xn_sa) && pqlk_aligned16(xn_obs);
   if (fast) {
     int64_t fb = (b + 15) / 16;
     if (fb > 2048) fb = 2048;
