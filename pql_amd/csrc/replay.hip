@@ -288,6 +288,7 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
   // (scalar, <= 31 per matrix: ld - cols < 32 + 3; pads are a few dozen bytes per row)
   const int sa_cols = L.O + L.A;
   const int npad_sa = (int)(ld_sa - sa_cols), npad_o = xn_obs ? (int)(ld_o - L.O) : 0;
+  const bool pad_vec = (sa_cols & 3) == 0 && (L.O & 3) == 0;
 
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
@@ -333,11 +334,20 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
         if (o_rew) o_rew[r] = x.x;
         if (o_done) o_done[r] = x.y;
       }
-      if (lane < npad_sa) {
-        if (x_sa) x_sa[r * ld_sa + sa_cols + lane] = 0.f;
-        if (xn_sa) xn_sa[r * ld_sa + sa_cols + lane] = 0.f;
+      if (pad_vec) {   // pads start on a 16-B boundary: one 16-B zero store per lane
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane < (npad_sa >> 2)) {
+          if (x_sa) *reinterpret_cast<float4*>(x_sa + r * ld_sa + sa_cols + 4 * lane) = z4;
+          if (xn_sa) *reinterpret_cast<float4*>(xn_sa + r * ld_sa + sa_cols + 4 * lane) = z4;
+        }
+        if (lane < (npad_o >> 2)) *reinterpret_cast<float4*>(xn_obs + r * ld_o + L.O + 4 * lane) = z4;
+      } else {
+        if (lane < npad_sa) {
+          if (x_sa) x_sa[r * ld_sa + sa_cols + lane] = 0.f;
+          if (xn_sa) xn_sa[r * ld_sa + sa_cols + lane] = 0.f;
+        }
+        if (lane < npad_o) xn_obs[r * ld_o + L.O + lane] = 0.f;
       }
-      if (lane < npad_o) xn_obs[r * ld_o + L.O + lane] = 0.f;
     }
   }
 }
