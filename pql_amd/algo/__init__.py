@@ -1,7 +1,4 @@
-"""Class-name -> file registry for algorithms, same contract as pql/algo/__init__.py."""
-from pathlib import Path
+"""Algorithm plugin table: `cfg.algo.name` ("Agent" + name for baselines) is looked up here by class name."""
+from pql_amd.utils.common import ClassIndex
 
-from pql_amd.utils.common import list_class_names
-
-cur_path = Path(__file__).resolve().parent
-alg_name_to_path = list_class_names(cur_path)
+alg_name_to_path = ClassIndex(__file__)

@@ -38,33 +38,36 @@ class DeviceTracker:
 
 class PQLActor:
     def __init__(self, env, cfg, env_offset=0, total_envs=None):
-        self.env = env
-        self.cfg = cfg
-        self.obs_dim = self.env.observation_space.shape
-        self.action_dim = self.env.action_space.shape[0]
+        self.env, self.cfg = env, cfg
+        self.obs_dim = env.observation_space.shape
+        self.action_dim = env.action_space.shape[0]
         self.sim_device = torch.device(f"{cfg.sim_device}")
         self.v_learner_device = torch.device(f"cuda:{cfg.algo.v_learner_gpu}")
         self.p_learner_device = torch.device(f"cuda:{cfg.algo.p_learner_gpu}")
-        self.env_offset, self.total_envs = int(env_offset), total_envs
-        self.actor = None
+        self.env_offset, self.total_envs = int(env_offset), total_envs   # position on the GLOBAL env axis (data parallel)
+        self.actor = None   # rollout replica of the policy, assigned by the driver
         self.obs = None
-        n = cfg.num_envs
-        self.return_tracker = DeviceTracker(cfg.algo.tracker_len, self.sim_device)
-        self.step_tracker = DeviceTracker(cfg.algo.tracker_len, self.sim_device)
-        self.current_returns = torch.zeros(n, dtype=torch.float32, device=self.sim_device)
-        self.current_lengths = torch.zeros(n, dtype=torch.float32, device=self.sim_device)
         if cfg.info_track_keys is not None:
             raise NotImplementedError("info_track_keys needs a simulator's info dict; out of scope")
-        self.obs_rms = RunningMeanStd(shape=self.obs_dim, device=self.sim_device) if cfg.algo.obs_norm else None
-        self.n_step_buffer = NStepReplay(self.obs_dim, self.action_dim, n, cfg.algo.nstep, device=self.sim_device)
-        noise = cfg.algo.noise
-        if noise.decay == "linear":
-            self.noise_scheduler = LinearSchedule(noise.std_max, noise.std_min, noise.lin_decay_iters)
-        elif noise.decay == "exp":
-            self.noise_scheduler = ExponentialSchedule(noise.std_max, noise.exp_decay_rate, noise.std_min)
-        else:
-            self.noise_scheduler = None
+        algo, n, dev = cfg.algo, cfg.num_envs, self.sim_device
+        self.return_tracker = DeviceTracker(algo.tracker_len, dev)
+        self.step_tracker = DeviceTracker(algo.tracker_len, dev)
+        self.current_returns = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.current_lengths = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.obs_rms = RunningMeanStd(shape=self.obs_dim, device=dev) if algo.obs_norm else None
+        self.n_step_buffer = NStepReplay(self.obs_dim, self.action_dim, n, algo.nstep, device=dev)
+        self.noise_scheduler = self._make_scheduler(algo.noise)
+        self._slabs = {}   # (N, T, .) trajectory slabs, allocated once per horizon length and reused
 
+    @staticmethod
+    def _make_scheduler(noise):
+        if noise.decay == "linear":
+            return LinearSchedule(noise.std_max, noise.std_min, noise.lin_decay_iters)
+        if noise.decay == "exp":
+            return ExponentialSchedule(noise.std_max, noise.exp_decay_rate, noise.std_min)
+        return None
+
+    # ---- small API kept from the reference ---------------------------------------------------
     def reset_agent(self):
         self.obs = self.env.reset()
 
@@ -76,64 +79,74 @@ class PQLActor:
             self.noise_scheduler.step()
 
     def get_actions(self, obs, sample=True):
-        if self.cfg.algo.obs_norm:
-            obs = self.obs_rms.normalize(obs)      # rollout side: no clamp (torch_util.py:83-85)
-        actions = self.actor(obs)
-        if sample:
-            noise = self.cfg.algo.noise
-            if noise.type == "fixed":
-                actions = add_normal_noise(actions, std=self.get_noise_std(), out_bounds=[-1., 1.])
-            elif noise.type == "mixed":
-                actions = add_mixed_normal_noise(actions, std_min=noise.std_min, std_max=noise.std_max, out_bounds=[-1., 1.],
-                                                 env_offset=self.env_offset, total_envs=self.total_envs)
-            else:
-                raise NotImplementedError(noise.type)
-        return actions
+        """Policy action on rollout-normalised observations (no +-5 clamp on this side, torch_util.py:83-85), plus
+        exploration noise: 'mixed' = per-env sigma spread over [std_min, std_max] along the global env axis."""
+        x = self.obs_rms.normalize(obs) if self.cfg.algo.obs_norm else obs
+        act = self.actor(x)
+        if not sample:
+            return act
+        noise = self.cfg.algo.noise
+        if noise.type == "mixed":
+            return add_mixed_normal_noise(act, std_min=noise.std_min, std_max=noise.std_max, out_bounds=[-1., 1.],
+                                          env_offset=self.env_offset, total_envs=self.total_envs)
+        if noise.type == "fixed":
+            return add_normal_noise(act, std=self.get_noise_std(), out_bounds=[-1., 1.])
+        raise NotImplementedError(noise.type)
+
+    # ---- rollout --------------------------------------------------------------------------------
+    def _trajectory_slabs(self, T):
+        sl = self._slabs.get(T)
+        if sl is None:
+            n, dev = self.cfg.num_envs, self.sim_device
+            O = self.obs_dim[0] if not isinstance(self.obs_dim, int) else self.obs_dim
+            mk = lambda *shape: torch.empty(shape, device=dev)  # noqa: E731
+            sl = dict(obs=mk(n, T, O), act=mk(n, T, self.action_dim), rew=mk(n, T, 1), nobs=mk(n, T, O), done=mk(n, T, 1))
+            self._slabs[T] = sl
+        return sl
 
     @torch.no_grad()
     def explore_env(self, env, timesteps: int, random: bool):
-        n, dev = self.cfg.num_envs, self.sim_device
-        O = self.obs_dim[0] if not isinstance(self.obs_dim, int) else self.obs_dim
-        traj_states = torch.empty((n, timesteps, O), device=dev)
-        traj_actions = torch.empty((n, timesteps, self.action_dim), device=dev)
-        traj_rewards = torch.empty((n, timesteps), device=dev)
-        traj_next_states = torch.empty((n, timesteps, O), device=dev)
-        traj_dones = torch.empty((n, timesteps), device=dev)
+        """Step the vectorised env `timesteps` times and return `(obs for the P-learner, 5-tuple for the V-learner,
+        env steps taken)` -- the contract of pql_actor.py:87-127.  Everything stays on the GPU and nothing synchronises
+        with the host: running statistics, trackers, the n-step window and the hand-off copies are all stream work."""
+        algo, n = self.cfg.algo, self.cfg.num_envs
+        sl = self._trajectory_slabs(timesteps)
         obs = self.obs
-        for i in range(timesteps):
-            if self.cfg.algo.obs_norm:
+        for t in range(timesteps):
+            if self.obs_rms is not None:
                 self.obs_rms.update(obs)
-            if random:
-                action = torch.rand((n, self.action_dim), device=dev) * 2.0 - 1.0
+            if random:   # warm-up: U(-1, 1) actions
+                action = torch.rand((n, self.action_dim), device=self.sim_device).mul_(2.0).sub_(1.0)
             else:
                 action = self.get_actions(obs, sample=True)
             next_obs, reward, done, info = env.step(action)
             self.update_tracker(reward, done, info)
-            if self.cfg.algo.handle_timeout:
+            if algo.handle_timeout:
                 done = handle_timeout(done, info)
-            traj_states[:, i] = obs
-            traj_actions[:, i] = action
-            traj_dones[:, i] = done
-            traj_rewards[:, i] = reward
-            traj_next_states[:, i] = next_obs
+            sl["obs"][:, t] = obs
+            sl["act"][:, t] = action
+            sl["rew"][:, t, 0] = reward
+            sl["nobs"][:, t] = next_obs
+            sl["done"][:, t, 0] = done
             obs = next_obs
         self.obs = obs
-        traj_rewards = self.cfg.algo.reward_scale * traj_rewards.reshape(n, timesteps, 1)
-        traj_dones = traj_dones.reshape(n, timesteps, 1)
-        obs, action, reward, next_obs, done = self.n_step_buffer.add_to_buffer(traj_states, traj_actions, traj_rewards,
-                                                                               traj_next_states, traj_dones)
-        act_data = obs.reshape(-1, O).to(self.p_learner_device, non_blocking=True)
-        cri_data = tuple(t.to(self.v_learner_device, non_blocking=True) for t in (obs, action, reward, next_obs, done))
-        return act_data, cri_data, timesteps * n
+        rew = sl["rew"] * algo.reward_scale
+        out = self.n_step_buffer.add_to_buffer(sl["obs"], sl["act"], rew, sl["nobs"], sl["done"])
+        O = out[0].shape[-1]
+        p_data = out[0].reshape(-1, O).to(self.p_learner_device, non_blocking=True)
+        v_data = tuple(x.to(self.v_learner_device, non_blocking=True) for x in out)
+        return p_data, v_data, timesteps * n
 
     def update_tracker(self, reward, done, info):
+        """Episode return / length windows, updated with masked scatters on the device (the reference's
+        `torch.where(done)[0]` + `.tolist()` stalls the stream every env step)."""
+        finished = done.bool()
         self.current_returns += reward
         self.current_lengths += 1
-        d = done.bool()
-        self.return_tracker.update(self.current_returns, d)
-        self.step_tracker.update(self.current_lengths, d)
-        self.current_returns.masked_fill_(d, 0)
-        self.current_lengths.masked_fill_(d, 0)
+        self.return_tracker.update(self.current_returns, finished)
+        self.step_tracker.update(self.current_lengths, finished)
+        self.current_returns.masked_fill_(finished, 0)
+        self.current_lengths.masked_fill_(finished, 0)
         return done
 
     def add_info_tracker_log(self, log_info):

@@ -1,0 +1,1 @@
+"""Synthetic vectorised environments (Isaac-Gym stand-ins)."""

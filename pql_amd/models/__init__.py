@@ -1,7 +1,4 @@
-"""Class-name -> file registry, same contract as pql/models/__init__.py:5-6."""
-from pathlib import Path
+"""Model plugin table: `cfg.algo.act_class` / `cfg.algo.cri_class` are looked up here by class name."""
+from pql_amd.utils.common import ClassIndex
 
-from pql_amd.utils.common import list_class_names
-
-cur_path = Path(__file__).resolve().parent
-model_name_to_path = list_class_names(cur_path)
+model_name_to_path = ClassIndex(__file__)

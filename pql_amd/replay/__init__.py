@@ -1,0 +1,1 @@
+"""Replay ring and n-step assembler on HBM."""

@@ -1,0 +1,1 @@
+"""Host-side helpers: config loader, plugin registry, noise, running statistics, logging."""

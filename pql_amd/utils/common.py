@@ -136,3 +136,15 @@ def preprocess_cfg(cfg):
         cfg.algo.reward_scale = TASK_REWARD_SCALE[task_name]
     if task_name in TASK_MAX_TIME and cfg.max_time == 3600:
         cfg.max_time = TASK_MAX_TIME[task_name]
+
+
+class ClassIndex(dict):
+    """{class name: defining file} for a package directory -- the reference's string-keyed plugin table
+    (`model_name_to_path` / `alg_name_to_path`), built by an AST scan so nothing is imported until selected."""
+
+    def __init__(self, package_file):
+        super().__init__(list_class_names(Path(package_file).resolve().parent))
+
+    def resolve(self, name):
+        """Load and return the class registered under `name`."""
+        return load_class_from_path(name, self[name])

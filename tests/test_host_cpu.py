@@ -117,3 +117,42 @@ def test_product_refuses_cpu_tensors():
         NStepReplay((3,), 2, 4, 3, device="cpu")
     with pytest.raises(PqlkError):
         TanhMLPPolicy((3,), 2)(torch.zeros(5, 3))      # CPU arena -> loud failure, never an eager fallback
+
+
+def test_checkpoint_roundtrip_in_reference_format(tmp_path):
+    """{'obs_rms','actor','critic'} with the reference's state_dict keys, loadable with
+    weights_only=True (nothing is unpickled)."""
+    from pql_amd.models.mlp import DoubleQ, TanhMLPPolicy
+    from pql_amd.utils.model_util import load_model, save_model
+    a, q = TanhMLPPolicy((8,), 2), DoubleQ((8,), 2)
+    rms = (torch.arange(8.0), torch.ones(8) * 2, 1e-4)
+    path = tmp_path / "model.pth"
+    save_model(path, a, q, rms)
+    raw = torch.load(path, weights_only=True)
+    assert sorted(raw) == ["actor", "critic", "obs_rms"] and "net_q2.net.6.bias" in raw["critic"] and "net.0.weight" in raw["actor"]
+    a2, q2 = TanhMLPPolicy((8,), 2), DoubleQ((8,), 2)
+    assert load_model(a2, "actor", path) and load_model(q2, "critic", path)
+    assert torch.equal(a2.arena.data, a.arena.data) and torch.equal(q2.arena.data, q.arena.data)
+    holder = type("R", (), {"mean": torch.zeros(8), "var": torch.ones(8), "epsilon": 0.0})()
+    assert load_model(holder, "obs_rms", path) and torch.equal(holder.mean, rms[0]) and holder.epsilon == 1e-4
+    with pytest.raises(KeyError):
+        load_model(a2, "policy", path)
+
+
+def test_noise_schedules_match_reference_semantics():
+    from pql_amd.utils.schedule_util import ExponentialSchedule, LinearSchedule
+    lin = LinearSchedule(0.8, 0.05, 4)
+    assert [round(lin.step(), 4) for _ in range(7)] == [0.8, 0.6125, 0.425, 0.2375, 0.05, 0.05, 0.05]
+    ex = ExponentialSchedule(0.8, 0.5, 0.05)
+    assert ex.total_iters == 4 and [round(ex.step(), 4) for _ in range(6)] == [0.4, 0.2, 0.1, 0.05, 0.025, 0.025]
+
+
+def test_config_composition_and_overrides():
+    from pql_amd.utils.cfg import load_cfg
+    c = load_cfg([])
+    assert (c.algo.name, c.algo.nstep, c.algo.critic_sample_ratio, c.algo.critic_actor_ratio) == ("PQL", 3, 8, 2)
+    assert int(c.algo.memory_size) == 5_000_000 and c.algo.noise.tgt_pol_noise_bound == 0.2 and c.sim_device == "cuda"
+    assert (c.algo.v_learner_gpu, c.algo.p_learner_gpu, c.algo.num_gpus, c.algo.distl, c.algo.num_atoms) == (1, 1, 2, False, 51)
+    d = load_cfg(["algo=ddpg_algo", "algo.batch_size=256", "num_envs=64", "task.name=Toy", "algo.noise.std_max=0.5"])
+    assert (d.algo.name, d.algo.update_times, d.algo.batch_size, d.num_envs, d.algo.noise.std_max) == ("DDPG", 8, 256, 64, 0.5)
+    assert d.algo.max_grad_norm == 0.5 and d.algo.tau == 0.05   # inherited through off_policy.yaml <- actor_critic.yaml
