@@ -88,7 +88,7 @@ def build_system(args, rank, world, device, pg):
     actor = PQLActor(env, cfg, env_offset=rank * args.num_envs, total_envs=world * args.num_envs)
     v = PQLVLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=pg)
     p = PQLPLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=pg)
-    if world > 1:   # replicated parameters: every rank starts from rank 0's weights
+    if pg is not None:   # replicated parameters: every rank starts from rank 0's weights
         for t in (v.critic.arena.data, p.actor.arena.data):
             if torch.distributed.get_backend(pg) == "gloo":
                 h = t.cpu(); torch.distributed.broadcast(h, src=0, group=pg); t.copy_(h)
@@ -305,7 +305,9 @@ def main():
     device = torch.device("cuda:0" if args.share_gpu else f"cuda:{local}")
     torch.cuda.set_device(device)
     pg = None
-    if world > 1:
+    if world > 1 or os.environ.get("PQL_FORCE_DP"):   # PQL_FORCE_DP=1: rehearse the RCCL path with a 1-rank group
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=device)   # RCCL
         else:
@@ -325,7 +327,7 @@ def main():
     sched = Schedule(actor, v, p, env, cfg, device, v_only=args.v_only)
 
     def barrier():
-        if world > 1:
+        if pg is not None:
             torch.distributed.barrier(group=pg)
 
     for _ in range(args.warmup):
@@ -341,7 +343,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     note(f"timed {args.steps} steps in {dt:.3f} s")
-    if world > 1:
+    if pg is not None:
         tt = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX, group=pg)
         dt = float(tt.item())
@@ -394,7 +396,7 @@ def main():
             note("cpu baseline done")
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if pg is not None:
         torch.distributed.destroy_process_group()
 
 

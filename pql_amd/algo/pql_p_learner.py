@@ -12,6 +12,7 @@ learn()  (reference :47-64)  ->  one launch sequence
 from __future__ import annotations
 
 import contextlib
+import os
 import ctypes as C
 import time
 from copy import deepcopy
@@ -36,6 +37,8 @@ class PQLPLearner:
         self.device = torch.device(f"cuda:{int(cfg.algo.p_learner_gpu)}")
         self.pg = process_group
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        # dp: the collective is issued even for a 1-rank group, so the RCCL path can be rehearsed on one GPU
+        self.dp = process_group is not None
         algo = cfg.algo
         act_class = load_class_from_path(algo.act_class, model_name_to_path[algo.act_class])
         hidden = _cfg_get(algo, "hidden_layers")
@@ -144,7 +147,7 @@ class PQLPLearner:
         self._step_post(ws)
 
     def _allreduce_grads(self, ws):
-        if self.world > 1:
+        if self.dp:
             allreduce_sum(ws["grads"], self.pg)
 
     def _step_post(self, ws):
@@ -195,7 +198,7 @@ class PQLPLearner:
         torch.cuda.set_rng_state(rng, self.device)
         g = torch.cuda.CUDAGraph()
         g_post = None
-        if self.world == 1:
+        if not self.dp:
             with torch.cuda.graph(g):
                 self._draw_and_step(ws)
         else:

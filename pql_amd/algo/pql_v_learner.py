@@ -15,6 +15,7 @@ is captured once into a hipGraph (through torch.cuda.CUDAGraph) and replayed.
 from __future__ import annotations
 
 import contextlib
+import os
 import ctypes as C
 import time
 from copy import deepcopy
@@ -136,6 +137,8 @@ class PQLVLearner:
         self.device = torch.device(f"cuda:{int(cfg.algo.v_learner_gpu)}")
         self.pg = process_group  # data-parallel group (RCCL); None = single GPU
         self.world = torch.distributed.get_world_size(process_group) if process_group is not None else 1
+        # dp: the collective is issued even for a 1-rank group, so the RCCL path can be rehearsed on one GPU
+        self.dp = process_group is not None
 
         algo = cfg.algo
         if algo.distl and "Distributional" not in algo.cri_class:
@@ -268,7 +271,7 @@ class PQLVLearner:
         self._step_post(ws)
 
     def _allreduce_grads(self, ws):
-        if self.world > 1:  # data-parallel: ONE collective per step, sum over ranks on RCCL; the mean is folded into
+        if self.dp:  # data-parallel: ONE collective per step, sum over ranks on RCCL; the mean is folded into
             allreduce_sum(ws["grads"], self.pg)                         # the optimiser's grad_scale
 
     def _step_post(self, ws):
@@ -327,7 +330,7 @@ class PQLVLearner:
         self._restore(snap)
         g = torch.cuda.CUDAGraph()
         g_post = None
-        if self.world == 1:
+        if not self.dp:
             with torch.cuda.graph(g):
                 self._draw_and_step(ws)
         else:   # two graphs around the RCCL all-reduce (kept eager: no collective is ever captured)
