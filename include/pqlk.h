@@ -259,6 +259,15 @@ int pqlk_polyak(float* target, const float* cur, int64_t n, float tau, pqlk_stre
 int pqlk_batch_moments(const float* x, int64_t ldx, int64_t n, int32_t cols, float* mean_out, float* var_out,
                        float* scratch, pqlk_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Synthetic vectorised environment step (the Isaac-Gym stand-in of BASELINE.json; not a reference component).
+ * Counter-based: outputs depend only on (seed, env_offset + env, t, column), so shards of the env axis reproduce
+ * slices of the global env.  next_obs ~ N(0,1) (N, obs_dim); reward = N(0,1) - 0.1 mean(action^2) (N);
+ * done ~ Bernoulli(p_done) as bytes (N).  Same arithmetic as pql_amd/envs/synthetic.py's torch-op definition. */
+int pqlk_synth_env_step(int64_t n, int32_t obs_dim, int32_t act_dim, uint32_t seed, uint32_t env_offset, uint32_t t,
+                        float p_done, const float* action, float* next_obs, float* reward, uint8_t* done,
+                        pqlk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,6 +12,7 @@ done ~ Bernoulli(1/episode_length), info['TimeLimit.truncated'] = False.
 from __future__ import annotations
 
 import math
+import os
 from types import SimpleNamespace
 
 import torch
@@ -40,6 +41,8 @@ class SyntheticVecEnv:
         self.t = 0
         self.env_ids = (torch.arange(self.num_envs, device=self.device, dtype=torch.int64) + int(env_offset))
         self._p_done = 1.0 / float(episode_length)
+        self.env_offset = int(env_offset)
+        self._no_trunc = None
         self._obs = None
 
     def _uniform(self, stream, width):
@@ -62,12 +65,34 @@ class SyntheticVecEnv:
     @torch.no_grad()
     def step(self, action):
         self.t += 1
+        if self.device.type == "cuda" and not os.environ.get("PQL_SYNTH_TORCH"):   # one HIP launch instead of ~150 elementwise torch launches
+            return self._step_hip(action)
+        return self._step_torch(action)
+
+    def _step_torch(self, action):
         next_obs = self._normal(1, self.obs_dim)
         reward = self._normal(2, 1).squeeze(1) - 0.1 * (action * action).mean(dim=1)
         done = self._uniform(7, 1).squeeze(1) < self._p_done
         info = {"TimeLimit.truncated": torch.zeros_like(done)}
         self._obs = next_obs
         return next_obs, reward, done, info
+
+    def _step_hip(self, action):
+        """Same transition as `_step_torch`, one launch (`pqlk_synth_env_step`, include/pqlk.h)."""
+        from pql_amd import _lib as L
+        n, dev = self.num_envs, self.device
+        next_obs = torch.empty((n, self.obs_dim), dtype=torch.float32, device=dev)
+        reward = torch.empty(n, dtype=torch.float32, device=dev)
+        done = torch.empty(n, dtype=torch.bool, device=dev)
+        act = action.to(torch.float32).contiguous()
+        with torch.cuda.device(dev):
+            L.check(L.lib.pqlk_synth_env_step(n, self.obs_dim, self.act_dim, self.seed & 0xFFFFFFFF, self.env_offset & 0xFFFFFFFF,
+                                              self.t & 0xFFFFFFFF, float(self._p_done), L.ptr(act), L.ptr(next_obs), L.ptr(reward),
+                                              L.ptr(done), L.stream(dev)))
+        if self._no_trunc is None:
+            self._no_trunc = torch.zeros(n, dtype=torch.bool, device=dev)
+        self._obs = next_obs
+        return next_obs, reward, done, {"TimeLimit.truncated": self._no_trunc}
 
 
 def create_task_env(cfg, num_envs=None, env_offset=0):

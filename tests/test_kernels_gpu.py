@@ -492,3 +492,32 @@ def test_fused_forward_ignores_columns_past_the_input_width(dev):
     y0 = output_view(lay, mlp_forward_raw(lay, arena, clean, L.ACT_TANH, packed=pk, stash_all=False), B).clone()
     y1 = output_view(lay, mlp_forward_raw(lay, arena, wide, L.ACT_TANH, packed=pk, stash_all=False), B)
     assert torch.equal(y0, y1) and torch.isfinite(y1).all()
+
+
+# --------------------------------------------------------------------------- synthetic env (Isaac-Gym stand-in)
+@pytest.mark.parametrize("n,O,A,off", [(257, 88, 16, 0), (4096, 211, 20, 4096), (33, 8, 2, 7)])
+def test_synthetic_env_kernel_equals_torch_definition(dev, n, O, A, off):
+    """The one-launch HIP env step computes the counter-based transition defined by the torch-op form: hashes,
+    uniforms and `done` bit-exact; Box-Muller normals within libm-vs-device transcendental rounding (1e-5)."""
+    from pql_amd.envs.synthetic import SyntheticVecEnv
+    a = SyntheticVecEnv(n, O, A, device=dev, seed=1234, episode_length=30, env_offset=off)
+    b = SyntheticVecEnv(n, O, A, device=dev, seed=1234, episode_length=30, env_offset=off)
+    a.reset(), b.reset()
+    for t in range(3):
+        act = torch.from_numpy(dd.uniform((n, A), 50 + t) * 2 - 1).to(dev)
+        o1, r1, d1, i1 = a.step(act)           # HIP
+        b.t += 1
+        o2, r2, d2, i2 = b._step_torch(act)    # torch ops on the same device
+        torch.cuda.synchronize()
+        assert d1.dtype == torch.bool and torch.equal(d1, d2)
+        assert not bool(i1["TimeLimit.truncated"].any())
+        np.testing.assert_allclose(o1.cpu().numpy(), o2.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(r1.cpu().numpy(), r2.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    # shards of the env axis reproduce slices of the global env
+    g = SyntheticVecEnv(2 * n, O, A, device=dev, seed=9, env_offset=0)
+    s = SyntheticVecEnv(n, O, A, device=dev, seed=9, env_offset=n)
+    g.reset(), s.reset()
+    act = torch.from_numpy(dd.uniform((2 * n, A), 77) * 2 - 1).to(dev)
+    og, rg, dg, _ = g.step(act)
+    os_, rs, ds, _ = s.step(act[n:])
+    assert torch.equal(og[n:], os_) and torch.equal(rg[n:], rs) and torch.equal(dg[n:], ds)
