@@ -1,19 +1,29 @@
-// Fused hidden-layer forward of an MLP: Linear -> ELU -> Linear -> ELU ... for one 32-row batch tile per block, all
-// hidden layers in ONE launch (reference: the nn.Sequential of pql/models/mlp.py:15-24 evaluated layer by layer).
+// Fused hidden-layer forward of an MLP: Linear -> ELU -> Linear -> ELU ... for one tile of 32 or 64 batch rows per block,
+// all hidden layers in ONE launch (reference: the nn.Sequential of pql/models/mlp.py:15-24 evaluated layer by layer).
 //
-// Why: at batch 8192 every per-layer GEMM launch pays a fixed ~15 us (launch gap, first-tile latency, and the 33 MB
+// Why: at batch 8192 every per-layer GEMM launch pays a fixed ~10-15 us (launch gap, first-tile latency, and the 33 MB
 // activation write that all blocks drain at once before the next launch can read it back) on top of 15-60 us of MFMA
-// time.  Here the activations of a 32-row tile never leave the CU: they ping-pong between two LDS buffers
-// ((32 x (width+4)) fp32 each, 132 KB for 512-wide layers), the only HBM traffic is the optional stash write (needed
-// by backward) and it is asynchronous.  Weights are streamed straight from L2 into MFMA operand registers: with one
-// 32-row tile per block a weight element is used exactly once per block, so an LDS stage would buy nothing; instead the
+// time.  Here the activations of a row tile never leave the CU: they live in ONE LDS buffer ((32 R) x (width + 4) fp32),
+// the only HBM traffic is the optional stash write (needed by backward).  Weights are streamed straight from L2 into
+// MFMA operand registers: a weight element is used once per row tile, so an LDS stage would buy nothing; instead the
 // weights are kept in a second, fragment-ordered copy (`pqlk_mlp_pack`) in which the 64 lanes of a wave read one
 // contiguous KiB per instruction:
 //     packed[layer][tile t = n/32][k8 = k/8][lane = (r, h)][j]  =  W[32 t + r][8 k8 + 4 h + j]
 // i.e. exactly the B-fragment quad of the k-ordering used by k_gemm (kk = 8 k8 + 4 h + j), so fused and unfused
-// paths accumulate every output element in the same order.
-// One wave per SIMD (4 waves / block, one block per CU at 512-wide layers), each wave owning TPW 32-column tiles and a
-// 4-deep register ring of weight quads (3 k8-groups = ~3k cycles of MFMA work in flight ahead of use).
+// paths accumulate every output element in the same order and stay bitwise equal.
+//
+// Block = 8 waves (two per SIMD, so one wave's waits hide behind the other's MFMAs).  Wave w owns output tiles
+// [w TPW, (w+1) TPW) of a layer (TPW = 1, 2 or 4 by layer width) for all R row tiles, and a D-deep register ring of
+// weight quads per tile.  A layer's outputs stay in the MFMA accumulators until every wave has finished reading the
+// layer's input (barrier A), then overwrite it (barrier B).  What the measurements behind this shape said:
+//  * R = 2 (64 rows, 132 KB of LDS at 512-wide layers): every weight quad feeds two row tiles, halving the VMEM
+//    instructions per MFMA.  Each global_load_dwordx4 costs MFMA issue slots wherever it is placed and whichever cache
+//    serves it (loads the MFMAs do not depend on, or that always hit the per-CU L1, cost the same ~15 % at R = 1; a
+//    deeper ring buys nothing), so fewer loads per MFMA is the lever: 155 -> 138 us on the twin critic of cfg #2.
+//  * The next layer's first ring stages are fetched BEFORE the epilogue, and the first ring group of a layer is peeled
+//    so that the previous layer's stash stores, which sit behind those loads in the in-order vmcnt queue, are counted
+//    (vmcnt(stores + ring - 1)) instead of drained.  The last group of a layer does not refill.
+//  * Biases are copied to LDS once; the epilogue must not wait on global loads queued behind the ring.
 #pragma once
 #include "pqlk_common.h"
 
@@ -28,88 +38,163 @@ struct FusedP {
   int dims[PQLK_MAX_LAYERS + 1];  // in (logical), h1, h2, ...
   long long net_stride, packed_net_stride;
   long long b_off[PQLK_MAX_LAYERS], p_off[PQLK_MAX_LAYERS], a_off[PQLK_MAX_LAYERS];
+#if defined(PQLK_FP_CLK)   // tuning probe only (tools/probes/fused_probe.hip): shader-clock stamps of one wave
+  long long* clk;
+#endif
 };
+
+#if defined(PQLK_FP_CLK)
+#define FP_TICK(i) if (clk && lane == 0) clk[i] = clock64()
+#define FP_CLKPARAM , long long* clk
+#define FP_CLKARG , clk
+#else
+#define FP_TICK(i)
+#define FP_CLKPARAM
+#define FP_CLKARG
+#endif
 
 __device__ __forceinline__ float fused_elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
-// in_off / out_off: float offsets of the two activation buffers inside the dynamic LDS array.  They are passed as
-// OFFSETS, not pointers: a runtime-selected pointer loses its address space, the reads become flat_load and every
-// wait degrades to `vmcnt(0) lgkmcnt(0)`, which drains the weight prefetch ring on each k-step.
+// All LDS addressing is by OFFSET into this array (a runtime-selected pointer loses its address space: the reads become
+// flat_load and every wait degrades to `vmcnt(0) lgkmcnt(0)`, which drains the weight ring on each step).
 extern __shared__ __attribute__((aligned(16))) float fsm[];
 
-template <int TPW, int NW>
-__device__ __forceinline__ void fused_layer(int in_off, int out_off, int buf_ld, int K,
-                                            int N, const float* __restrict__ packed_l, const float* __restrict__ bias_l,
-                                            float* __restrict__ gout, int g_ld, int row0, int B, int wave, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-  const int K8 = K >> 3;
-  const int ntiles = N >> 5;
-  for (int tbase = wave * TPW; tbase < ntiles; tbase += NW * TPW) {
-    f32x16f acc[TPW];
+constexpr int FUSED_NW = 8;   // waves per block
+#ifndef PQLK_FUSED_DEEP
+#define PQLK_FUSED_DEEP 4     // ring depth in reduction steps of 8 (8 and 16 measured no faster)
+#endif
+
+// one ring group: up to D reduction steps of 8, each consuming ring slot s and (REFILL) refilling it D steps ahead
+template <int R, int TPW, int TM, int D, bool REFILL>
+__device__ __forceinline__ void fused_group(f32x16f (&acc)[R][TPW], float4 (&bq)[D][TM], const float4* const (&wp)[TPW],
+                                            const float4* __restrict__ lds4, int abase, int buf_ld4, int k8, int K8, int steps) {
 #pragma unroll
-    for (int j = 0; j < TPW; ++j)
+  for (int s = 0; s < D; ++s) {
+    if (s < steps) {
+      float4 a[R];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
-    const float4* wp[TPW];
+      for (int i = 0; i < R; ++i) a[i] = lds4[abase + 32 * i * buf_ld4 + 2 * (k8 + s)];
+      // unconditional, clamped refill: straight-line code lets the compiler keep the other ring stages in flight behind
+      // a counted s_waitcnt vmcnt(N); a branch here degrades every wait to vmcnt(0)
+      const int kn = min(k8 + s + D, K8 - 1);
+      // MFMA order t-major over the R x TPW accumulators, so consecutive MFMAs are independent
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) wp[j] = reinterpret_cast<const float4*>(packed_l) + (long long)(tbase + j) * K8 * 64 + lane;
-    float4 bq[4][TPW];
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int j = 0; j < TPW; ++j) bq[s][j] = wp[j][s * 64];   // K8 >= 4
-    __builtin_amdgcn_sched_barrier(0);
-    for (int k8 = 0; k8 < K8; k8 += 4) {  // K is a multiple of 32 -> K8 a multiple of 4
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float4 a = *reinterpret_cast<const float4*>(&fsm[in_off + r * buf_ld + 8 * (k8 + s) + 4 * h]);
-        const float av[4] = {a.x, a.y, a.z, a.w};
+      for (int t = 0; t < 4; ++t) {
 #pragma unroll
         for (int j = 0; j < TPW; ++j) {
-          const float bv[4] = {bq[s][j].x, bq[s][j].y, bq[s][j].z, bq[s][j].w};
+          const float bv = t == 0 ? bq[s][j].x : t == 1 ? bq[s][j].y : t == 2 ? bq[s][j].z : bq[s][j].w;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t], av[t], acc[j], 0, 0, 0);
+          for (int i = 0; i < R; ++i) {
+            const float av = t == 0 ? a[i].x : t == 1 ? a[i].y : t == 2 ? a[i].z : a[i].w;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av, acc[i][j], 0, 0, 0);
+          }
+          if (REFILL && t == 3) {
+            bq[s][j] = wp[j][kn * 64];
+            __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: hipcc otherwise sinks the loads to just before use
+          }
         }
-        // unconditional refill (index clamped at the tail): straight-line code lets the compiler keep the other
-        // three ring stages in flight behind a counted s_waitcnt vmcnt(N); a branch here degrades every wait to vmcnt(0)
-        const int kn = min(k8 + s + 4, K8 - 1);
-#pragma unroll
-        for (int j = 0; j < TPW; ++j) bq[s][j] = wp[j][kn * 64];
-        __builtin_amdgcn_sched_barrier(0);  // keep the refill HERE: hipcc otherwise sinks the loads to just before use
-      }
-    }
-    // epilogue: lane (r, h) owns row r, columns 32*tile + 8q + 4h + {0..3} (transposed-tile accumulator layout)
-    const bool row_ok = row0 + r < B;
-#pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = 32 * (tbase + j) + 8 * q + 4 * h;
-        const float4 b4 = *reinterpret_cast<const float4*>(bias_l + col);
-        float4 v;
-        v.x = fused_elu(acc[j][4 * q] + b4.x);
-        v.y = fused_elu(acc[j][4 * q + 1] + b4.y);
-        v.z = fused_elu(acc[j][4 * q + 2] + b4.z);
-        v.w = fused_elu(acc[j][4 * q + 3] + b4.w);
-        *reinterpret_cast<float4*>(&fsm[out_off + r * buf_ld + col]) = v;
-        if (gout && row_ok) *reinterpret_cast<float4*>(gout + (long long)(row0 + r) * g_ld + col) = v;
       }
     }
   }
 }
 
-#ifndef PQLK_FUSED_WAVES
-#define PQLK_FUSED_WAVES 8   // waves per block: 8 = two per SIMD, so one wave's LDS / L2 waits hide behind the other's MFMAs
-#endif
-__global__ __launch_bounds__(64 * PQLK_FUSED_WAVES) void k_mlp_fwd_fused(FusedP p) {
-  constexpr int NW = PQLK_FUSED_WAVES;
+// ring <- the first D steps of (layer, wave)'s tiles; indices clamped so that idle waves / short layers stay in bounds
+template <int TM, int D>
+__device__ __forceinline__ void fused_ring_fill(float4 (&bq)[D][TM], const float4* __restrict__ packed_l, int K8, int ntiles, int tpw,
+                                                int wave, int lane) {
+  const float4* w[TM];
+#pragma unroll
+  for (int j = 0; j < TM; ++j) w[j] = packed_l + (long long)min(wave * tpw + j, ntiles - 1) * K8 * 64 + lane;
+#pragma unroll
+  for (int s = 0; s < D; ++s) {
+    const int ks = min(s, K8 - 1) * 64;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) bq[s][j] = w[j][ks];
+  }
+}
+
+template <int R, int TPW, int TM, int D>
+__device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, int K8, int ntiles, const float4* __restrict__ packed_l,
+                                            int bias_lds4, float* __restrict__ gout, int g_ld, int row0, int B, int wave, int lane,
+                                            const float4* __restrict__ packed_n, int K8n, int ntiles_n, int tpw_n FP_CLKPARAM) {
+  const int r = lane & 31, h = lane >> 5;
+  const int t0 = wave * TPW;
+  const bool active = t0 < ntiles;   // wave-uniform
+  const float4* lds4 = reinterpret_cast<const float4*>(fsm);
+  FP_TICK(0);
+  f32x16f acc[R][TPW];
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  if (active) {
+    const float4* wp[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) wp[j] = packed_l + (long long)min(t0 + j, ntiles - 1) * K8 * 64 + lane;
+    const int abase = r * buf_ld4 + h;
+    const int K8full = K8 - (K8 % D);
+    const int G = K8full / D;
+    const bool rem = D > 4 && K8full < K8;   // K8 % D == 4 (K8 is a multiple of 4): ring slots 0..3 hold those steps
+    if (G > 1) fused_group<R, TPW, TM, D, true>(acc, bq, wp, lds4, abase, buf_ld4, 0, K8, D);   // peeled (see header)
+    for (int g = 1; g < G - 1; ++g) fused_group<R, TPW, TM, D, true>(acc, bq, wp, lds4, abase, buf_ld4, g * D, K8, D);
+    if (G >= 1) {
+      if (rem) fused_group<R, TPW, TM, D, true>(acc, bq, wp, lds4, abase, buf_ld4, (G - 1) * D, K8, D);
+      else fused_group<R, TPW, TM, D, false>(acc, bq, wp, lds4, abase, buf_ld4, (G - 1) * D, K8, D);
+    }
+    if (rem) fused_group<R, TPW, TM, D, false>(acc, bq, wp, lds4, abase, buf_ld4, K8full, K8, 4);
+  }
+  FP_TICK(1);
+  if (packed_n) fused_ring_fill<TM, D>(bq, packed_n, K8n, ntiles_n, tpw_n, wave, lane);   // ahead of this layer's epilogue
+  __syncthreads();   // A: every wave is done reading this layer's input
+  FP_TICK(2);
+  if (active) {
+    // lane (r, h) owns row r of each row tile, columns 32*tile + 8q + 4h + {0..3} (transposed-tile accumulator layout)
+    float4* out4 = reinterpret_cast<float4*>(fsm);
+    const bool full = row0 + 32 * R <= B;   // block-uniform: no per-row guard on the stash stores
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      if (t0 + j < ntiles) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c4 = 8 * (t0 + j) + 2 * q + h;   // float4 column
+          const float4 b4 = lds4[bias_lds4 + c4];
+#pragma unroll
+          for (int i = 0; i < R; ++i) {
+            const int row = row0 + 32 * i + r;
+            float4 v;
+            v.x = fused_elu(acc[i][j][4 * q] + b4.x);
+            v.y = fused_elu(acc[i][j][4 * q + 1] + b4.y);
+            v.z = fused_elu(acc[i][j][4 * q + 2] + b4.z);
+            v.w = fused_elu(acc[i][j][4 * q + 3] + b4.w);
+            out4[(32 * i + r) * buf_ld4 + c4] = v;
+            if (gout && (full || row < B)) *reinterpret_cast<float4*>(gout + (long long)row * g_ld + 4 * c4) = v;
+          }
+        }
+      }
+    }
+  }
+  FP_TICK(3);
+  __syncthreads();   // B: the next layer's input is in place
+  FP_TICK(4);
+}
+
+// R row tiles of 32 per block; TM = widest per-wave tile count any layer needs (2: widths <= 512, 4: <= 1024)
+template <int R, int TM>
+__global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
+  // four tiles per wave: 16 MFMAs per step already cover the L2 latency with a 2-deep ring (and 4 x 4 quads would spill)
+  constexpr int NW = FUSED_NW, D = TM >= 4 ? 2 : PQLK_FUSED_DEEP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#if defined(PQLK_FP_CLK)
+  const long long c_start = clock64();
+#endif
   // XCD-aware block -> (net, row tile) map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share
   // an L2), and a twin critic's fragment-ordered weights are 2 x 1.8 MB against a 4 MB L2: with both nets on every
   // XCD the weight stream thrashes L2 and falls back to the Infinity Cache.  Even XCD groups take net 0, odd ones
   // net 1, so each L2 keeps ONE net's weights resident.  (Speed only: any placement computes the same result.)
   int net, tile;
-  const int tiles = (p.B + 31) >> 5;
+  const int tiles = (p.B + 32 * R - 1) / (32 * R);
   if (p.n_nets == 2 && (tiles & 3) == 0) {
     const int b = blockIdx.x, g = b & 7, i = b >> 3;
     net = g & 1;
@@ -118,39 +203,61 @@ __global__ __launch_bounds__(64 * PQLK_FUSED_WAVES) void k_mlp_fwd_fused(FusedP 
     net = blockIdx.x / tiles;
     tile = blockIdx.x % tiles;
   }
-  const int row0 = tile * 32;
-  const int boff[2] = {0, 32 * p.buf_ld};
-  {  // stage the input tile (pad columns of X are zero by contract; rows past B are zero-filled)
-    const int k0 = (p.dims[0] + 31) & ~31;
-    const int cpr = k0 >> 2;
-    for (int i = tid; i < 32 * cpr; i += 64 * NW) {
+  const int row0 = tile * 32 * R;
+  const int buf_ld4 = p.buf_ld >> 2;
+  const float4* packed_net = reinterpret_cast<const float4*>(p.packed + (long long)net * p.packed_net_stride);
+  auto tpw_of = [](int ntiles) { return ntiles > 2 * NW ? 4 : ntiles > NW ? 2 : 1; };
+  float4 bq[D][TM];
+  // ring of layer 0, issued before the input tile is staged
+  fused_ring_fill<TM, D>(bq, packed_net + (p.p_off[0] >> 2), ((p.dims[0] + 31) & ~31) >> 3, p.dims[1] >> 5, tpw_of(p.dims[1] >> 5), wave,
+                         lane);
+  float4* out4 = reinterpret_cast<float4*>(fsm);
+  const int bias4 = 32 * R * buf_ld4;   // float4 offset of the bias table: layer l at bias4 + l * (buf_ld4 - 1)
+  for (int l = 0; l < p.n_hidden; ++l) {
+    const float4* src = reinterpret_cast<const float4*>(p.params + (long long)net * p.net_stride + p.b_off[l]);
+    for (int i = tid; i < (p.dims[l + 1] >> 2); i += 64 * NW) out4[bias4 + l * (buf_ld4 - 1) + i] = src[i];
+  }
+  {  // stage the input tile (rows past B are zero-filled)
+    const int k0 = (p.dims[0] + 31) & ~31, cpr = k0 >> 2, w = p.dims[0];
+    for (int i = tid; i < 32 * R * cpr; i += 64 * NW) {
       const int row = i / cpr, c4 = i % cpr;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row0 + row < p.B) v = *reinterpret_cast<const float4*>(p.X + (long long)(row0 + row) * p.ldx + 4 * c4);
       // columns past the logical input width are forced to zero here, so X may be a wider matrix whose extra columns
       // hold something else (the target actor reads its observations straight out of the critic's [obs | action] tile)
-      const int c = 4 * c4, w = p.dims[0];
+      const int c = 4 * c4;
       if (c + 3 >= w) {
         if (c >= w) v.x = 0.f;
         if (c + 1 >= w) v.y = 0.f;
         if (c + 2 >= w) v.z = 0.f;
         v.w = 0.f;
       }
-      *reinterpret_cast<float4*>(&fsm[row * p.buf_ld + 4 * c4]) = v;
+      out4[row * buf_ld4 + c4] = v;
     }
   }
   __syncthreads();
   for (int l = 0; l < p.n_hidden; ++l) {
-    const int K = (p.dims[l] + 31) & ~31, N = p.dims[l + 1];
-    const float* packed_l = p.packed + (long long)net * p.packed_net_stride + p.p_off[l];
-    const float* bias_l = p.params + (long long)net * p.net_stride + p.b_off[l];
+    const int K8 = ((p.dims[l] + 31) & ~31) >> 3, N = p.dims[l + 1], ntiles = N >> 5;
+    const float4* packed_l = packed_net + (p.p_off[l] >> 2);
+    const int bias_l = bias4 + l * (buf_ld4 - 1);
     float* gout = (p.stash_all || l == p.n_hidden - 1) ? p.acts + p.a_off[l] + (long long)net * p.B * N : nullptr;
-    const int ntiles = N >> 5;
-    const int in = boff[l & 1], out = boff[(l & 1) ^ 1];
-    if (ntiles % (4 * NW) == 0) fused_layer<4, NW>(in, out, p.buf_ld, K, N, packed_l, bias_l, gout, N, row0, p.B, wave, lane);
-    else if (ntiles % (2 * NW) == 0) fused_layer<2, NW>(in, out, p.buf_ld, K, N, packed_l, bias_l, gout, N, row0, p.B, wave, lane);
-    else fused_layer<1, NW>(in, out, p.buf_ld, K, N, packed_l, bias_l, gout, N, row0, p.B, wave, lane);
-    __syncthreads();
+    const bool last = l + 1 == p.n_hidden;
+    const float4* packed_n = last ? nullptr : packed_net + (p.p_off[l + 1] >> 2);
+    const int K8n = last ? 1 : N >> 3, ntiles_n = last ? 1 : p.dims[l + 2] >> 5;
+    const int tpw = tpw_of(ntiles), tpw_n = tpw_of(ntiles_n);
+#if defined(PQLK_FP_CLK)
+    long long* clk = (blockIdx.x == 8 && wave == 0) ? p.clk + 8 + 8 * l : nullptr;
+    if (l == 0 && clk && lane == 0) { p.clk[0] = c_start; p.clk[1] = clock64(); }
+#endif
+    if (TM >= 4 && tpw == 4)
+      fused_layer<R, (TM >= 4 ? 4 : 1), TM, D>(bq, buf_ld4, K8, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n,
+                                               ntiles_n, tpw_n FP_CLKARG);
+    else if (tpw == 2)
+      fused_layer<R, 2, TM, D>(bq, buf_ld4, K8, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n, ntiles_n,
+                               tpw_n FP_CLKARG);
+    else
+      fused_layer<R, 1, TM, D>(bq, buf_ld4, K8, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n, ntiles_n,
+                               tpw_n FP_CLKARG);
   }
 }
 

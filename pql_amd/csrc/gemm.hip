@@ -16,6 +16,7 @@
 // A 32-wide reduction step is consumed as 4 groups (k8) x 4 MFMAs (t); lane half h supplies reduction
 // index kk = 8*k8 + 4*h + t.  A and B use the same map, so any such bijection is a valid dot product;
 // this one lets k-contiguous operands be fetched with one ds_read_b128 per four MFMAs.
+#include <cstdlib>
 #include "pqlk_common.h"
 #include "skinny.h"
 #include "fused.h"
@@ -499,15 +500,21 @@ extern "C" int64_t pqlk_mlp_bwd_ws_floats(const PqlMlpDesc* d, int64_t b, int32_
 
 // ================================================================================================
 // fused hidden-layer path (fused.h)
+// fusable: at least one hidden layer, hidden widths multiples of 32 and <= 1024 (4 output tiles per wave), and one
+// 32-row activation tile + the bias table within the 160 KB of LDS
+static size_t fused_lds_bytes(const PqlMlpDesc* d, int buf_ld, int R) {
+  return ((size_t)32 * R * buf_ld + (size_t)(d->n_layers - 1) * (buf_ld - 4)) * sizeof(float);
+}
+
 static bool fusable(const PqlMlpDesc* d, int* buf_ld_out) {
   if (d->n_layers < 2) return false;
   int64_t w = pqlk_ld(d->dims[0]);
   for (int l = 1; l < d->n_layers; ++l) {
-    if (d->dims[l] % 32 != 0) return false;
+    if (d->dims[l] % 32 != 0 || d->dims[l] > 1024) return false;
     w = d->dims[l] > w ? d->dims[l] : w;
   }
   const int64_t buf_ld = w + 4;
-  if (2 * 32 * buf_ld * (int64_t)sizeof(float) > 160 * 1024) return false;
+  if (fused_lds_bytes(d, (int)buf_ld, 1) > 160 * 1024) return false;
   if (buf_ld_out) *buf_ld_out = (int)buf_ld;
   return true;
 }
@@ -550,6 +557,10 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
   int buf_ld = 0;
   if (!fusable(d, &buf_ld)) return PQLK_E_UNSUPPORTED;
   p.X = x; p.params = params; p.packed = packed; p.acts = acts;
+#if defined(PQLK_FP_CLK)
+  extern long long* g_fp_clk;
+  p.clk = g_fp_clk;
+#endif
   p.B = (int)b; p.ldx = (int)ldx; p.n_hidden = d->n_layers - 1; p.stash_all = stash_all; p.buf_ld = buf_ld; p.n_nets = d->n_nets;
   p.net_stride = pqlk_mlp_net_stride(d); p.packed_net_stride = packed_net_stride(d);
   int64_t p_off = 0;
@@ -561,15 +572,35 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
     p.b_off[l] = b_off; p.p_off[l] = p_off; p.a_off[l] = a_off;
     p_off += (int64_t)d->dims[l + 1] * pqlk_ld(d->dims[l]);
   }
-  const size_t shmem = (size_t)2 * 32 * buf_ld * sizeof(float);
-  static size_t attr_set = 0;
-  if (shmem > attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd_fused), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024);
-    if (e != hipSuccess) return -(int)e;
-    attr_set = 160 * 1024;
+  // rows per block: 64 (R = 2) when no hidden layer is wider than 512 (two output tiles per wave, 132 KB of LDS) and the
+  // halved grid still fills the 256 CUs about as well -- cost model: rounds x rows per block, 32-row blocks ~15 % less
+  // efficient per row.  PQLK_FUSED_ROWS = 32 / 64 overrides (tuning).
+  bool wide = false;
+  for (int l = 1; l < d->n_layers; ++l) wide = wide || d->dims[l] > 512;
+  int R = 1;
+  if (!wide && fused_lds_bytes(d, buf_ld, 2) <= 160 * 1024) {
+    const int64_t b1 = ((b + 31) / 32) * d->n_nets, b2 = ((b + 63) / 64) * d->n_nets;
+    const double c1 = 1.15 * (double)((b1 + 255) / 256), c2 = 2.0 * (double)((b2 + 255) / 256);
+    if (c2 <= c1) R = 2;
+    static const int forced = [] { const char* e = getenv("PQLK_FUSED_ROWS"); return e ? atoi(e) : 0; }();
+    if (forced == 32) R = 1;
+    if (forced == 64) R = 2;
   }
-  hipLaunchKernelGGL(k_mlp_fwd_fused, dim3((unsigned)(((b + 31) / 32) * d->n_nets)), dim3(64 * PQLK_FUSED_WAVES), shmem, st, p);
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* ks[3] = {reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 2>), reinterpret_cast<const void*>(&k_mlp_fwd_fused<2, 2>),
+                         reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 4>)};
+    for (const void* k : ks) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return -(int)e;
+    }
+    attr_set = true;
+  }
+  const size_t shmem = fused_lds_bytes(d, buf_ld, R);
+  const dim3 grid((unsigned)(((b + 32 * R - 1) / (32 * R)) * d->n_nets)), block(64 * FUSED_NW);
+  if (wide) hipLaunchKernelGGL((k_mlp_fwd_fused<1, 4>), grid, block, shmem, st, p);
+  else if (R == 2) hipLaunchKernelGGL((k_mlp_fwd_fused<2, 2>), grid, block, shmem, st, p);
+  else hipLaunchKernelGGL((k_mlp_fwd_fused<1, 2>), grid, block, shmem, st, p);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }

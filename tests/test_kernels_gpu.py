@@ -411,8 +411,13 @@ def test_batch_moments(dev):
 
 
 # --------------------------------------------------------------------------- fused hidden-layer forward
-@pytest.mark.parametrize("dims,nets,B", [([104, 512, 512, 256, 1], 2, 8192), ([88, 512, 256, 128, 16], 1, 777),
-                                          ([231, 512, 256, 128, 51], 2, 100), ([10, 32, 64, 2], 1, 33)])
+@pytest.mark.parametrize("dims,nets,B", [([104, 512, 512, 256, 1], 2, 8192),    # 64-row blocks, XCD-aware placement
+                                          ([104, 512, 512, 256, 1], 2, 8131),    # 64-row blocks, ragged last tile
+                                          ([88, 512, 256, 128, 16], 1, 777),     # 32-row blocks, ragged, idle waves at 128
+                                          ([231, 512, 256, 128, 51], 2, 100),
+                                          ([10, 32, 64, 2], 1, 33),              # reduction shorter than the weight ring
+                                          ([40, 1024, 768, 288, 3], 1, 500),     # four / three tiles per wave, odd tile count
+                                          ([72, 96, 1], 2, 16384)])              # one hidden layer
 def test_fused_forward_equals_per_layer_path(dev, dims, nets, B):
     """k_mlp_fwd_fused (activations resident in LDS, fragment-ordered weights) accumulates every element in the same
     order as the per-layer k_gemm path: outputs and every stashed activation must be bit-identical."""
@@ -440,7 +445,8 @@ def test_fused_forward_equals_per_layer_path(dev, dims, nets, B):
 def test_fused_path_is_declined_for_unsupported_widths(dev):
     from pql_amd.models.mlp import ArenaLayout, PackedWeights
     assert PackedWeights(ArenaLayout([8, 100, 64, 1], 1), dev).tensor is None      # hidden width not a multiple of 32
-    assert PackedWeights(ArenaLayout([8, 1024, 1024, 1], 1), dev).tensor is None   # two LDS activation buffers > 160 KB
+    assert PackedWeights(ArenaLayout([8, 1056, 64, 1], 1), dev).tensor is None     # more than four output tiles per wave
+    assert PackedWeights(ArenaLayout([2000, 64, 64, 1], 1), dev).tensor is None    # a 32-row input tile > 160 KB of LDS
     assert PackedWeights(ArenaLayout([8, 1], 1), dev).tensor is None               # no hidden layer
 
 
