@@ -116,12 +116,22 @@ __device__ __forceinline__ void fused_ring_fill(float4 (&bq)[D][TM], const float
 template <int R, int TPW, int TM, int D>
 __device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, int K8, int ntiles, const float4* __restrict__ packed_l,
                                             int bias_lds4, float* __restrict__ gout, int g_ld, int row0, int B, int wave, int lane,
-                                            const float4* __restrict__ packed_n, int K8n, int ntiles_n, int tpw_n FP_CLKPARAM) {
+                                            const float4* __restrict__ packed_n, int K8n, int ntiles_n, int tpw_n,
+                                            float* __restrict__ gprev, int nprev4 FP_CLKPARAM) {
   const int r = lane & 31, h = lane >> 5;
   const int t0 = wave * TPW;
   const bool active = t0 < ntiles;   // wave-uniform
   const float4* lds4 = reinterpret_cast<const float4*>(fsm);
   FP_TICK(0);
+  // Deferred stash: this layer's INPUT buffer is the previous layer's output.  Writing it to HBM from here, spread over
+  // the main loop (thread tid takes float4 elements tid, tid + 512, ... of the (32 R) x nprev tile: whole 1 KiB lines per
+  // wave instruction), replaces the epilogue's burst of 32-B-per-row stores that every block issues at the same moment
+  // and that is store-issue bound (~10 B/clk/CU: 12-18 k cycles per 512-wide layer at R = 2).  Full tiles only.
+  float4* gprev4 = reinterpret_cast<float4*>(gprev) + (long long)row0 * nprev4;
+  const int srows = gprev ? 32 * R : 0;
+  const int tid = wave * 64 + lane;
+  int srow = tid / nprev4, sc4 = tid % nprev4;                               // element tid of the row-major tile ...
+  const int sdq = (64 * FUSED_NW) / nprev4, sdm = (64 * FUSED_NW) % nprev4;   // ... and the stride of 512 elements
   f32x16f acc[R][TPW];
 #pragma unroll
   for (int i = 0; i < R; ++i)
@@ -138,12 +148,24 @@ __device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, in
     const int G = K8full / D;
     const bool rem = D > 4 && K8full < K8;   // K8 % D == 4 (K8 is a multiple of 4): ring slots 0..3 hold those steps
     if (G > 1) fused_group<R, TPW, TM, D, true>(acc, bq, wp, lds4, abase, buf_ld4, 0, K8, D);   // peeled (see header)
-    for (int g = 1; g < G - 1; ++g) fused_group<R, TPW, TM, D, true>(acc, bq, wp, lds4, abase, buf_ld4, g * D, K8, D);
+    for (int g = 1; g < G - 1; ++g) {
+      if (srow < srows) {   // deferred stash of the previous layer (see above): one coalesced 16-B store per group
+        gprev4[(long long)srow * nprev4 + sc4] = lds4[srow * buf_ld4 + sc4];
+        srow += sdq; sc4 += sdm;
+        if (sc4 >= nprev4) { sc4 -= nprev4; ++srow; }
+      }
+      fused_group<R, TPW, TM, D, true>(acc, bq, wp, lds4, abase, buf_ld4, g * D, K8, D);
+    }
     if (G >= 1) {
       if (rem) fused_group<R, TPW, TM, D, true>(acc, bq, wp, lds4, abase, buf_ld4, (G - 1) * D, K8, D);
       else fused_group<R, TPW, TM, D, false>(acc, bq, wp, lds4, abase, buf_ld4, (G - 1) * D, K8, D);
     }
     if (rem) fused_group<R, TPW, TM, D, false>(acc, bq, wp, lds4, abase, buf_ld4, K8full, K8, 4);
+  }
+  while (srow < srows) {   // what the main loop did not cover (idle waves, short reductions)
+    gprev4[(long long)srow * nprev4 + sc4] = lds4[srow * buf_ld4 + sc4];
+    srow += sdq; sc4 += sdm;
+    if (sc4 >= nprev4) { sc4 -= nprev4; ++srow; }
   }
   FP_TICK(1);
   if (packed_n) fused_ring_fill<TM, D>(bq, packed_n, K8n, ntiles_n, tpw_n, wave, lane);   // ahead of this layer's epilogue
@@ -204,6 +226,7 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
     tile = blockIdx.x % tiles;
   }
   const int row0 = tile * 32 * R;
+  const bool full_tile = row0 + 32 * R <= p.B;
   const int buf_ld4 = p.buf_ld >> 2;
   const float4* packed_net = reinterpret_cast<const float4*>(p.packed + (long long)net * p.packed_net_stride);
   auto tpw_of = [](int ntiles) { return ntiles > 2 * NW ? 4 : ntiles > NW ? 2 : 1; };
@@ -240,8 +263,13 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
     const int K8 = ((p.dims[l] + 31) & ~31) >> 3, N = p.dims[l + 1], ntiles = N >> 5;
     const float4* packed_l = packed_net + (p.p_off[l] >> 2);
     const int bias_l = bias4 + l * (buf_ld4 - 1);
-    float* gout = (p.stash_all || l == p.n_hidden - 1) ? p.acts + p.a_off[l] + (long long)net * p.B * N : nullptr;
     const bool last = l + 1 == p.n_hidden;
+    // layer l's output goes to HBM either from its own epilogue (last hidden layer, ragged tiles) or from the next
+    // layer's main loop (deferred: full tiles of a stashing forward)
+    const bool defer = p.stash_all && full_tile;
+    float* gout = (last || (p.stash_all && !full_tile)) ? p.acts + p.a_off[l] + (long long)net * p.B * N : nullptr;
+    float* gprev = (defer && l > 0) ? p.acts + p.a_off[l - 1] + (long long)net * p.B * p.dims[l] : nullptr;
+    const int nprev4 = p.dims[l] >> 2;
     const float4* packed_n = last ? nullptr : packed_net + (p.p_off[l + 1] >> 2);
     const int K8n = last ? 1 : N >> 3, ntiles_n = last ? 1 : p.dims[l + 2] >> 5;
     const int tpw = tpw_of(ntiles), tpw_n = tpw_of(ntiles_n);
@@ -251,13 +279,13 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
 #endif
     if (TM >= 4 && tpw == 4)
       fused_layer<R, (TM >= 4 ? 4 : 1), TM, D>(bq, buf_ld4, K8, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n,
-                                               ntiles_n, tpw_n FP_CLKARG);
+                                               ntiles_n, tpw_n, gprev, nprev4 FP_CLKARG);
     else if (tpw == 2)
       fused_layer<R, 2, TM, D>(bq, buf_ld4, K8, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n, ntiles_n,
-                               tpw_n FP_CLKARG);
+                               tpw_n, gprev, nprev4 FP_CLKARG);
     else
       fused_layer<R, 1, TM, D>(bq, buf_ld4, K8, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n, ntiles_n,
-                               tpw_n FP_CLKARG);
+                               tpw_n, gprev, nprev4 FP_CLKARG);
   }
 }
 
