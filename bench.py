@@ -370,10 +370,12 @@ def main():
         "gflop_per_v_step": f_v / 1e9, "gflop_per_p_step": f_p / 1e9,
     }
     if rank == 0:
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # from the committed rocprofv3 --pmc passes
-        if os.path.exists(tpath) and args.hidden == "512,512,256" and args.task == "AllegroHand" and args.batch == 8192:
-            traffic = json.load(open(tpath))
+        traffic, traffic_src = {}, None
+        import glob
+        tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))   # committed rocprofv3 --pmc passes; newest tag
+        if tpaths and args.hidden == "512,512,256" and args.task == "AllegroHand" and args.batch == 8192:
+            traffic = json.load(open(tpaths[-1]))
+            traffic_src = os.path.relpath(tpaths[-1], ROOT)
         # roofline of the dominant kernel family: the fp32-MFMA GEMMs of one V step (k_gemm<...>)
         ms = gemm_section_ms(v)
         achieved = f_v / (ms * 1e-3) / 1e12
@@ -381,7 +383,7 @@ def main():
                             "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("mfma_family_per_v_step_bytes"),
                             "traffic_note": "bytes at the L2<->fabric boundary per V step (FETCH_SIZE x2 + WRITE_SIZE, PMC passes in "
-                                            "profiles/r01_pmc_traffic.json); the family is MFMA-bound, not HBM-bound",
+                                            f"{traffic_src}); the family is MFMA-bound, not HBM-bound",
                             "ms_per_launch_group": ms}
         gms = gather_ms(v)
         rec_ld = v.memory.ring.rec_ld
