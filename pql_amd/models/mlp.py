@@ -242,6 +242,7 @@ class MLPNet(FusedMLP):
         if use_batchnorm:
             raise NotImplementedError("BatchNorm MLP (CrossQ) is out of scope")
         super().__init__(in_dim, out_dim, hidden_layers, n_nets=1, out_act=L.ACT_NONE)
+        self.init_kwargs = dict(in_dim=_first(in_dim), out_dim=int(out_dim), hidden_layers=self.layout.dims[1:-1])
 
     def forward(self, x):
         return self._run(x)[0]
@@ -252,6 +253,7 @@ class TanhMLPPolicy(FusedMLP):
 
     def __init__(self, state_dim, act_dim, hidden_layers=None):
         super().__init__(state_dim, act_dim, hidden_layers, n_nets=1, out_act=L.ACT_TANH)
+        self.init_kwargs = dict(state_dim=_first(state_dim), act_dim=int(act_dim), hidden_layers=self.layout.dims[1:-1])
 
     def forward(self, state):
         return self._run(state)[0]
@@ -266,6 +268,8 @@ class DoubleQ(FusedMLP):
     def __init__(self, state_dim, act_dim, hidden_layers=None, out_dim=1):
         self.state_dim, self.act_dim = _first(state_dim), int(act_dim)
         super().__init__(self.state_dim + self.act_dim, out_dim, hidden_layers, n_nets=2, out_act=L.ACT_NONE)
+        # constructor arguments as plain data: lets a module cross a process boundary as (class, kwargs, state_dict)
+        self.init_kwargs = dict(state_dim=self.state_dim, act_dim=self.act_dim, hidden_layers=self.layout.dims[1:-1], out_dim=int(out_dim))
 
     def _heads(self, state, action):
         return self._run(torch.cat((state, action), dim=1))
@@ -289,6 +293,8 @@ class DistributionalDoubleQ(DoubleQ):
         self.device = device
         self.v_min, self.v_max, self.num_atoms = v_min, v_max, int(num_atoms)
         self.z_atoms = torch.linspace(v_min, v_max, num_atoms, device=device)  # plain attribute, as mlp.py:253
+        self.init_kwargs = dict(state_dim=self.state_dim, act_dim=self.act_dim, v_min=v_min, v_max=v_max, num_atoms=self.num_atoms,
+                                device=str(device), hidden_layers=self.layout.dims[1:-1])
 
     def get_q1_q2(self, state, action):
         y = self._heads(state, action)

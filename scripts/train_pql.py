@@ -14,7 +14,6 @@ all-reduced over RCCL.
 """
 import os
 import sys
-import time
 from copy import deepcopy
 from itertools import count
 
@@ -29,14 +28,18 @@ from pql_amd.algo.pql_v_learner import PQLVLearner  # noqa: E402
 from pql_amd.envs.synthetic import create_task_env  # noqa: E402
 from pql_amd.utils.cfg import load_cfg  # noqa: E402
 from pql_amd.utils.common import capture_keyboard_interrupt, preprocess_cfg, set_random_seed  # noqa: E402
+from pql_amd.utils.evaluator import Evaluator  # noqa: E402
 from pql_amd.utils.logger import MetricLogger  # noqa: E402
 
 
-def should_stop(cfg, start_time, step):
-    """Evaluator.check_if_should_stop (pql/utils/evaluator.py:34-38)."""
-    if cfg.max_step is not None:
-        return step > cfg.max_step
-    return (time.time() - start_time) > cfg.max_time
+def agree_to_stop(stop, pg, device):
+    """Data parallel: every rank must leave the loop in the same iteration (the next one opens with collectives), and a
+    wall-clock criterion can differ between ranks -- take rank 0's verdict."""
+    if pg is None:
+        return stop
+    flag = torch.tensor([1.0 if stop else 0.0], device=device)
+    torch.distributed.broadcast(flag, src=0, group=pg)
+    return bool(flag.item())
 
 
 def main(cfg):
@@ -78,8 +81,9 @@ def main(cfg):
     pql_actor.actor = deepcopy(actor).to(sim_device)
 
     logger = MetricLogger(cfg.logging.get("jsonl") if cfg.get("logging") else None) if rank == 0 else None
-    start_time = time.time()
     global_steps = 0
+    # evaluation beside training (train_pql.py:55,171-185): rank 0 only; every rank keeps the stop criterion
+    evaluator = Evaluator(cfg=cfg, wandb_run=None, enabled=rank == 0)
     pql_actor.reset_agent()
     p_data, v_data, steps = pql_actor.explore_env(env, cfg.algo.warm_up, random=True)
     global_steps += steps * world
@@ -99,6 +103,8 @@ def main(cfg):
             v_learner.learn()
             if k % p_every == p_every - 1:
                 p_learner.learn()
+        if rank == 0 and evaluator.parent.poll():
+            logger.log(evaluator.parent.recv(), global_steps)
         if rank == 0 and iter_t % cfg.algo.log_freq == 0:
             log_info = {
                 "train/critic_loss": critic_loss, "train/actor_loss": actor_loss,
@@ -108,8 +114,17 @@ def main(cfg):
             logger.log(log_info, global_steps)
             if iter_t % cfg.algo.eval_freq == 0:
                 logger.table(global_steps, log_info)
-        if should_stop(cfg, start_time, global_steps):
+        if rank == 0 and iter_t % cfg.algo.eval_freq == 0:
+            evaluator.eval_policy(pql_actor.actor, v_learner.critic, normalizer=pql_actor.obs_rms, step=global_steps)
+        stop = evaluator.check_if_should_stop(global_steps)
+        if cfg.max_step is None:
+            stop = agree_to_stop(stop, pg, sim_device)
+        if stop:
             break
+    if rank == 0:
+        while evaluator.parent.pending():   # evaluations still in flight when training stops
+            logger.log(evaluator.parent.recv(), global_steps)
+        evaluator.close()
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -156,3 +156,78 @@ def test_config_composition_and_overrides():
     d = load_cfg(["algo=ddpg_algo", "algo.batch_size=256", "num_envs=64", "task.name=Toy", "algo.noise.std_max=0.5"])
     assert (d.algo.name, d.algo.update_times, d.algo.batch_size, d.num_envs, d.algo.noise.std_max) == ("DDPG", 8, 256, 64, 0.5)
     assert d.algo.max_grad_norm == 0.5 and d.algo.tau == 0.05   # inherited through off_policy.yaml <- actor_critic.yaml
+
+
+# --------------------------------------------------------------------------- evaluator
+def _reference_style_eval(cfg, policy, states):
+    """pql/utils/evaluator.py:41-121 restated with the host-side Tracker (the form the reference runs)."""
+    from pql_amd.envs.synthetic import create_task_env
+    from pql_amd.utils.common import Tracker
+    n = int(cfg.eval_num_envs)
+    env = create_task_env(cfg, num_envs=n)
+    ret_t, len_t = Tracker(n), Tracker(n)
+    cur_r, cur_l = torch.zeros(n), torch.zeros(n)
+    obs = env.reset()
+    for _ in range(env.max_episode_length):
+        x = (obs - states[0]) / torch.sqrt(states[1] + states[2]) if cfg.algo.obs_norm else obs
+        obs, reward, done, _ = env.step(policy(x))
+        cur_r += reward; cur_l += 1
+        idx = torch.where(done)[0]
+        ret_t.update(cur_r[idx]); len_t.update(cur_l[idx])
+        cur_r[idx] = 0; cur_l[idx] = 0
+    return {"eval/return": ret_t.mean(), "eval/episode_length": len_t.mean()}
+
+
+def test_evaluator_in_process_engine(tmp_path):
+    """Cooperative evaluator: same numbers as the reference's rollout loop, results appear after enough polls, the best
+    model is kept, and the stop criterion follows evaluator.py:34-38."""
+    from types import SimpleNamespace
+    from pql_amd.utils.cfg import load_cfg
+    from pql_amd.utils.evaluator import Evaluator
+    cfg = load_cfg(["task.name=Toy", "task.episode_length=20", "eval_num_envs=7", "device=cpu", "eval_steps_per_poll=6", "max_step=1000"])
+    A = 2
+    policy = lambda x: torch.tanh(x[:, :A] * 0.5)   # noqa: E731
+    mean, var = torch.linspace(-1, 1, 8), torch.linspace(0.5, 2, 8)
+    norm = SimpleNamespace(get_states=lambda device=None: (mean, var, 1e-4))
+    ev = Evaluator(cfg, wandb_run=SimpleNamespace(dir=str(tmp_path)))
+    assert not ev.parent.poll()
+    ev.eval_policy(policy, None, step=5, normalizer=norm)
+    polls = 0
+    while not ev.parent.poll():
+        polls += 1
+        assert polls < 10
+    assert polls == 3            # 20 steps at 6 per poll: the 4th poll enqueues the last 2 and finds the result
+    got = ev.parent.recv()
+    want = _reference_style_eval(cfg, policy, (mean, var, 1e-4))
+    assert got.keys() == want.keys()
+    for k in want:
+        assert abs(got[k] - want[k]) <= 1e-9 * max(1.0, abs(want[k])), (k, got[k], want[k])
+    ckpt = torch.load(tmp_path / "model.pth", weights_only=True)
+    assert torch.equal(ckpt["obs_rms"][0], mean) and ckpt["actor"] == {} and ckpt["critic"] == {}
+    # a worse policy later does not overwrite the best checkpoint; recv() on an unfinished job drives it to the end
+    (tmp_path / "model.pth").unlink()
+    ev.eval_policy(lambda x: torch.full((x.shape[0], A), 1.0), None, step=6, normalizer=norm)   # action penalty -> lower return
+    worse = ev.parent.recv()
+    assert worse["eval/return"] < got["eval/return"] and not (tmp_path / "model.pth").exists()
+    assert ev.parent.pending() == 0
+    assert not ev.check_if_should_stop(1000) and ev.check_if_should_stop(1001)
+    cfg2 = load_cfg(["device=cpu", "max_time=0", "task.name=Toy", "eval_num_envs=2"])
+    ev2 = Evaluator(cfg2, enabled=False)
+    assert ev2.check_if_should_stop(0) and not ev2.parent.poll()
+
+
+def test_evaluator_module_spec_round_trip_is_plain_data():
+    """Subprocess mode ships (class name, kwargs, CPU state_dict); the spec must survive pickle and name every argument the
+    constructor needs."""
+    import inspect, pickle
+    import pql_amd.models.mlp as M
+    from pql_amd.utils.evaluator import module_to_spec
+    for mod in (M.TanhMLPPolicy((8,), 2, hidden_layers=[64, 32]), M.DoubleQ((8,), 2, hidden_layers=[64, 32]),
+                M.DistributionalDoubleQ((8,), 2, num_atoms=11, device="cpu", hidden_layers=[32, 32])):
+        spec = pickle.loads(pickle.dumps(module_to_spec(mod)))
+        assert spec["cls"] == type(mod).__name__
+        params = inspect.signature(type(mod).__init__).parameters
+        assert set(spec["kwargs"]) <= set(params)
+        clone = type(mod)(**spec["kwargs"])
+        clone.load_state_dict(spec["state"])
+        assert torch.equal(clone.arena.data, mod.arena.data)

@@ -293,3 +293,52 @@ def test_data_parallel_two_ranks_match_single_gpu_step(golden, dev):
         assert ret[r]["steps"] == 3
     # different seeds-per-rank draws differ, but parameters are replicated: identical after the all-reduced steps
     assert np.array_equal(ret[0]["graph"], ret[1]["graph"])
+
+
+# --------------------------------------------------------------------------- evaluator
+@pytest.mark.parametrize("subprocess_mode", [False, True])
+def test_evaluator_on_gpu_matches_plain_rollout(dev, tmp_path, subprocess_mode):
+    """In-process (own HIP stream, cooperative polls) and subprocess (pipe protocol) evaluators both reproduce a plain
+    rollout loop of the same actor on the same synthetic env, and leave a loadable best checkpoint."""
+    from types import SimpleNamespace
+    from pql_amd.envs.synthetic import create_task_env
+    from pql_amd.models.mlp import DoubleQ, TanhMLPPolicy
+    from pql_amd.utils.cfg import load_cfg
+    from pql_amd.utils.common import Tracker
+    from pql_amd.utils.evaluator import Evaluator
+    from pql_amd.utils.model_util import load_model
+    from pql_amd.utils.torch_util import RunningMeanStd
+    cfg = load_cfg(["task.name=Toy", "task.episode_length=40", "eval_num_envs=150", "device=cuda:0", "eval_steps_per_poll=16",
+                    f"eval_subprocess={subprocess_mode}"])
+    torch.manual_seed(3)
+    actor, critic = TanhMLPPolicy((8,), 2).to(dev), DoubleQ((8,), 2).to(dev)
+    rms = RunningMeanStd(shape=(8,), device=dev)
+    rms.update(torch.randn(512, 8, device=dev) * 2 + 0.5)
+    # plain loop, host-side Tracker (the reference's form)
+    n = 150
+    env = create_task_env(cfg, num_envs=n)
+    rt, lt = Tracker(n), Tracker(n)
+    cr, cl = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    obs = env.reset()
+    with torch.no_grad():
+        for _ in range(env.max_episode_length):
+            obs, rew, done, _ = env.step(actor(rms.normalize(obs)))
+            cr += rew; cl += 1
+            idx = torch.where(done)[0]
+            rt.update(cr[idx]); lt.update(cl[idx])
+            cr[idx] = 0; cl[idx] = 0
+    ev = Evaluator(cfg, wandb_run=SimpleNamespace(dir=str(tmp_path)))
+    ev.eval_policy(actor, critic, step=1, normalizer=rms)
+    actor.arena.data.zero_()      # the evaluation must run on the snapshot taken at eval_policy time
+    if not subprocess_mode:
+        polls = 0
+        while not ev.parent.poll():
+            polls += 1
+            assert polls < 100000
+    got = ev.parent.recv()
+    ev.close()
+    assert abs(got["eval/return"] - rt.mean()) < 1e-5 and abs(got["eval/episode_length"] - lt.mean()) < 1e-5
+    a2 = TanhMLPPolicy((8,), 2).to(dev)
+    assert load_model(a2, "actor", str(tmp_path / "model.pth")) and float(a2.arena.data.abs().sum()) > 0
+    holder = RunningMeanStd(shape=(8,), device=dev)
+    assert load_model(holder, "obs_rms", str(tmp_path / "model.pth")) and torch.allclose(holder.mean, rms.mean)
