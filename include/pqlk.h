@@ -260,6 +260,40 @@ int pqlk_batch_moments(const float* x, int64_t ldx, int64_t n, int32_t cols, flo
                        float* scratch, pqlk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * SAC on the same kernels (reference pql/algo/sac.py:138-156, pql/models/mlp.py:144-174,
+ * pql/utils/torch_util.py:15-65).
+ *
+ * Squashed-Gaussian policy head.  y (B, ld_y) = [ mu(A) | log_std(A) | pad ] is the policy MLP's output
+ * (pqlk_mlp_forward with PQLK_ACT_NONE), eps (B, A) contiguous the standard-normal draw of Normal.rsample:
+ *     std = exp(clamp(log_std, -5, 5));  u = mu + eps * std;  a = tanh(u)
+ *     logp = sum_j [ -((u - mu)^2) / (2 std^2) - log(std) - log(sqrt(2 pi)) - 2 (log 2 - u - softplus(-2u)) ]
+ * act (B, ld_act) receives a in columns [0, A) (pass a pointer into the critic's [obs | action] tile); logp (B).
+ * eps == NULL => the deterministic action tanh(mu) (get_actions(sample=False)); logp is not written.  A <= 64. */
+int pqlk_sg_head_forward(const float* y, int64_t ld_y, const float* eps, int64_t b, int32_t act_dim,
+                         float* act, int64_t ld_act, float* logp, pqlk_stream_t stream);
+
+/* Backward of the head: dy (B, ld_y) <- d loss / d [mu | log_std] (pad columns written as zero) given
+ * da (B, ld_da) = d loss / d a and d loss / d logp = glp_scale * exp(*log_alpha) for every row
+ * (log_alpha: device scalar, NULL => factor 1).  dy feeds pqlk_mlp_backward of the policy MLP. */
+int pqlk_sg_head_backward(const float* y, int64_t ld_y, const float* eps, const float* act, int64_t ld_act,
+                          const float* da, int64_t ld_da, const float* log_alpha, float glp_scale,
+                          int64_t b, int32_t act_dim, float* dy, pqlk_stream_t stream);
+
+/* Entropy term of the SAC target (sac.py:140-142): column 0 of each target-critic net,
+ * qt[n * net_stride + r * ld] -= exp(*log_alpha) * logp[r]; pqlk_td_mse_loss then forms
+ * r + (1 - d) gamma^n (min(q1, q2) - alpha logp). */
+int pqlk_sac_entropy_shift(float* qt, int64_t ld, int64_t net_stride, int32_t n_nets, const float* logp,
+                           const float* log_alpha, int64_t b, pqlk_stream_t stream);
+
+/* Temperature terms (sac.py:146-156), one launch: with m = mean(logp) and alpha = exp(*log_alpha),
+ *   grad_out[0] = alpha_loss_out[0] = alpha * (-m - target_entropy)   (the alpha loss and its gradient w.r.t. log_alpha
+ *                                                                      have the same value; either may be NULL)
+ *   actor_loss_ring[*slot_dev % ring_len] += alpha * m                (completes mean(alpha logp - Q) after pqlk_dpg_loss) */
+int pqlk_sac_alpha_terms(const float* logp, int64_t b, const float* log_alpha, float target_entropy,
+                         float* grad_out, float* alpha_loss_out, float* actor_loss_ring,
+                         const int32_t* slot_dev, int32_t ring_len, pqlk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Synthetic vectorised environment step (the Isaac-Gym stand-in of BASELINE.json; not a reference component).
  * Counter-based: outputs depend only on (seed, env_offset + env, t, column), so shards of the env axis reproduce
  * slices of the global env.  next_obs ~ N(0,1) (N, obs_dim); reward = N(0,1) - 0.1 mean(action^2) (N);

@@ -473,3 +473,68 @@ class DDPGRef:
         self.aopt.apply(list(torch.autograd.grad(aloss, self.actor)), hp.max_grad_norm)
         polyak_ref([*self.t1, *self.t2], [p.detach() for p in cp], hp.tau)
         return float(closs.detach()), float(aloss.detach())
+
+
+# ------------------------------------------------------------------------------------------------ SAC
+LOG_SQRT_2PI = math.log(math.sqrt(2 * math.pi))
+
+
+def squashed_gaussian_ref(params, obs, eps):
+    """TanhDiagGaussianMLPPolicy.get_actions_logprob (pql/models/mlp.py:144-174) with the draw `eps` of Normal.rsample
+    supplied: SquashedNormal = TanhTransform(cache_size=1) over Normal(mu, exp(clamp(log_std, -5, 5)))
+    (pql/utils/torch_util.py:15-65; torch.distributions.Normal.rsample / log_prob).  Returns (a (B,A), logp (B,1))."""
+    mu, log_std = mlp_forward_ref(params, obs).chunk(2, dim=-1)
+    std = log_std.clamp(-5, 5).exp()
+    u = mu + eps * std
+    a = u.tanh()
+    jac = 2.0 * (math.log(2.0) - u - F.softplus(-2.0 * u))          # TanhTransform.log_abs_det_jacobian on the cached u
+    base = -((u - mu) ** 2) / (2 * std ** 2) - std.log() - LOG_SQRT_2PI
+    return a, ((0.0 - jac) + base).sum(-1, keepdim=True)
+
+
+class SACRef:
+    """AgentSAC.update_net inner iteration (pql/algo/sac.py:98-108,138-156), no_tgt_actor=True, learned temperature:
+    shared batch (normalised without clamp), critic step on the entropy-regularised n-step target, actor step through
+    the UPDATED critic, temperature step, Polyak on the critic."""
+
+    def __init__(self, obs_dim, act_dim, hp: HyperRef, capacity, actor, q1, q2, alpha_lr=5e-3, alpha=None):
+        self.hp = hp
+        self.actor = [p.clone().requires_grad_(True) for p in actor]
+        self.q1 = [p.clone().requires_grad_(True) for p in q1]
+        self.q2 = [p.clone().requires_grad_(True) for p in q2]
+        self.t1 = [p.detach().clone() for p in self.q1]; self.t2 = [p.detach().clone() for p in self.q2]
+        self.aopt = AdamWRef(self.actor, lr=hp.actor_lr)
+        self.copt = AdamWRef([*self.q1, *self.q2], lr=hp.critic_lr)
+        self.fixed_alpha = alpha
+        self.log_alpha = torch.zeros(1, requires_grad=True)
+        self.alpha_opt = AdamWRef([self.log_alpha], lr=alpha_lr)
+        self.target_entropy = -act_dim
+        self.ring = RingRef(capacity, obs_dim, act_dim)
+        self.norm = None
+
+    def alpha(self):
+        return self.log_alpha.detach().exp() if self.fixed_alpha is None else self.fixed_alpha
+
+    def update_once(self, idx, eps_next, eps_cur):
+        hp = self.hp
+        obs, act, rew, nobs, done = self.ring.gather(idx)
+        if hp.obs_norm:
+            obs = normalize_ref(obs, self.norm, clamp=False); nobs = normalize_ref(nobs, self.norm, clamp=False)
+        with torch.no_grad():
+            na, nlogp = squashed_gaussian_ref(self.actor, nobs, eps_next)
+            tq = qmin_ref(self.t1, self.t2, nobs, na) - self.alpha() * nlogp
+            tgt = rew + (1 - done) * (hp.gamma ** hp.nstep) * tq
+        c1, c2 = twin_forward_ref(self.q1, self.q2, obs, act)
+        closs = F.mse_loss(c1, tgt) + F.mse_loss(c2, tgt)
+        cp = [*self.q1, *self.q2]
+        self.copt.apply(list(torch.autograd.grad(closs, cp)), hp.max_grad_norm)
+        frozen1 = [p.detach() for p in self.q1]; frozen2 = [p.detach() for p in self.q2]
+        a, logp = squashed_gaussian_ref(self.actor, obs, eps_cur)
+        aloss = (self.alpha() * logp - qmin_ref(frozen1, frozen2, obs, a)).mean()
+        self.aopt.apply(list(torch.autograd.grad(aloss, self.actor)), hp.max_grad_norm)
+        alpha_loss = None
+        if self.fixed_alpha is None:
+            alpha_loss = (self.log_alpha.exp() * (-logp - self.target_entropy).detach()).mean()
+            self.alpha_opt.apply(list(torch.autograd.grad(alpha_loss, [self.log_alpha])), hp.max_grad_norm)
+        polyak_ref([*self.t1, *self.t2], [p.detach() for p in cp], hp.tau)
+        return float(closs.detach()), float(aloss.detach()), None if alpha_loss is None else float(alpha_loss.detach())

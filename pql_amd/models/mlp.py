@@ -259,6 +259,47 @@ class TanhMLPPolicy(FusedMLP):
         return self._run(state)[0]
 
 
+class TanhDiagGaussianMLPPolicy(FusedMLP):
+    """mlp.py:144-174: MLP -> [mu | log_std], a = tanh(mu + eps * exp(clamp(log_std, -5, 5))) (SquashedNormal), with the
+    summed log-probability.  The head runs as one HIP launch (`pqlk_sg_head_forward`); the learner-side backward is
+    `pqlk_sg_head_backward` (pql_amd/algo/sac.py).  Inference-only API here (no autograd through the sample)."""
+
+    log_std_min, log_std_max = -5, 5
+
+    def __init__(self, state_dim, act_dim, hidden_layers=None):
+        self.act_dim = int(act_dim)
+        super().__init__(state_dim, 2 * self.act_dim, hidden_layers, n_nets=1, out_act=L.ACT_NONE)
+        self.init_kwargs = dict(state_dim=_first(state_dim), act_dim=self.act_dim, hidden_layers=self.layout.dims[1:-1])
+
+    @torch.no_grad()
+    def _head(self, state, eps, want_logp):
+        L.require_gpu(self.arena, "parameter arena")
+        x_pad = pad_cols(state.to(torch.float32), self.layout.ld_in)
+        B, dev, A = x_pad.shape[0], x_pad.device, self.act_dim
+        y = output_view(self.layout, mlp_forward_raw(self.layout, self.arena.data, x_pad, L.ACT_NONE), B)[0]
+        act = torch.empty((B, A), dtype=torch.float32, device=dev)
+        logp = torch.empty((B, 1), dtype=torch.float32, device=dev) if want_logp else None
+        with torch.cuda.device(dev):
+            L.check(L.lib.pqlk_sg_head_forward(L.ptr(y), y.stride(0), L.ptr(eps), B, A, L.ptr(act), A, L.ptr(logp), L.stream(dev)))
+        return act, logp
+
+    def forward(self, state, sample=False):
+        return self.get_actions(state, sample=sample)
+
+    def get_actions(self, state, sample=True, eps=None):
+        """sample=True: rsample (eps ~ N(0,1) drawn here unless supplied); False: the distribution mean tanh(mu)."""
+        if sample and eps is None:
+            eps = torch.empty((state.shape[0], self.act_dim), dtype=torch.float32, device=state.device).normal_()
+        return self._head(state, eps.contiguous() if sample else None, False)[0]
+
+    def get_actions_logprob(self, state, eps=None):
+        """-> (actions, None, log_prob (B, 1)); the middle slot is the reference's distribution object."""
+        if eps is None:
+            eps = torch.empty((state.shape[0], self.act_dim), dtype=torch.float32, device=state.device).normal_()
+        act, logp = self._head(state, eps.contiguous(), True)
+        return act, None, logp
+
+
 class DoubleQ(FusedMLP):
     """mlp.py:186-203: twin Q(s,a) heads on cat(state, action)."""
 

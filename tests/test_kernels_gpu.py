@@ -527,3 +527,49 @@ def test_synthetic_env_kernel_equals_torch_definition(dev, n, O, A, off):
     og, rg, dg, _ = g.step(act)
     os_, rs, ds, _ = s.step(act[n:])
     assert torch.equal(og[n:], os_) and torch.equal(rg[n:], rs) and torch.equal(dg[n:], ds)
+
+
+# --------------------------------------------------------------------------- SAC policy head
+@pytest.mark.parametrize("tag", ["kat_toy", "kat_allegro"])
+def test_squashed_gaussian_head_golden(golden, dev, tag):
+    """pqlk_sg_head_forward / _backward (+ the MLP under them) vs the reference's TanhDiagGaussianMLPPolicy with the
+    rsample draw injected: actions and log-prob within 1e-5 relative, parameter gradients of
+    mean(0.3 logp - <a, w>) within the gradient bar used for the other heads.  kat_allegro has log_std beyond the
+    +-5 clamp and u deep in tanh saturation (|u| ~ 300)."""
+    from pql_amd import _lib as L
+    from pql_amd.models.mlp import TanhDiagGaussianMLPPolicy, default_splits, mlp_forward_raw, output_view, pad_cols
+    g = golden("sac")
+    O, A, B = (int(v) for v in g[f"{tag}_meta"])
+    state = dd.mlp_state(O, 2 * A, 61)
+    if A > 2:
+        state["net.6.bias"] = state["net.6.bias"].copy()
+        state["net.6.bias"][A:] = np.linspace(-6.5, 6.5, A).astype(np.float32)
+    pol = TanhDiagGaussianMLPPolicy((O,), A).to(dev)
+    pol.load_state_dict({k: T(v) for k, v in state.items()})
+    x = T(dd.uniform((B, O), 62, -2, 2)).to(dev)
+    eps = T(g[f"{tag}_eps"]).to(dev)
+    act, _, logp = pol.get_actions_logprob(x, eps=eps)
+    np.testing.assert_allclose(act.cpu().numpy(), g[f"{tag}_act"], atol=1e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), g[f"{tag}_logp"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(pol.get_actions(x, sample=False).cpu().numpy(), g[f"{tag}_mean_act"], atol=1e-6)
+    np.testing.assert_allclose(pol(x).cpu().numpy(), g[f"{tag}_mean_act"], atol=1e-6)   # forward(sample=False)
+    # backward of mean(0.3 logp - <a, w>): d/da = -w / B, d/dlogp = 0.3 / B
+    lay = pol.layout
+    x_pad = pad_cols(x, lay.ld_in)
+    acts = mlp_forward_raw(lay, pol.arena.data, x_pad, L.ACT_NONE)
+    y = output_view(lay, acts, B)[0]
+    w = T(dd.uniform((A,), 63, -1, 1)).to(dev)
+    da = (-w / B).repeat(B, 1).contiguous()
+    dy = torch.full((1, B, lay.ld_out), 7.0, device=dev)
+    L.check(L.lib.pqlk_sg_head_backward(L.ptr(y), lay.ld_out, L.ptr(eps), L.ptr(act), A, L.ptr(da), A, None, 0.3 / B, B, A, L.ptr(dy),
+                                        L.stream(dev)))
+    assert torch.all(dy[0, :, 2 * A:] == 0)
+    splits = default_splits(B)
+    grads = torch.empty_like(pol.arena.data); ws = torch.empty(lay.bwd_ws_floats(B, splits), device=dev)
+    L.check(L.lib.pqlk_mlp_backward(C.byref(lay.desc), L.ptr(pol.arena.data), L.ptr(x_pad), lay.ld_in, B, L.ptr(acts), L.ptr(dy),
+                                    L.ptr(grads), splits, None, 0, 0, 0, None, 0, L.ptr(ws), ws.numel(), L.stream(dev)))
+    for l in range(lay.n_layers):
+        for kind, view in (("weight", lay.weight(grads, 0, l)), ("bias", lay.bias(grads, 0, l))):
+            np.testing.assert_allclose(dd.summarize(view.cpu().numpy()), g[f"{tag}_g_net.{2 * l}.{kind}"], rtol=2e-4, atol=2e-6,
+                                       err_msg=f"{kind} {l}")
+    np.testing.assert_allclose(lay.bias(grads, 0, lay.n_layers - 1).cpu().numpy(), g[f"{tag}_g_last_b"], rtol=2e-4, atol=2e-6)

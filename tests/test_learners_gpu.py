@@ -342,3 +342,95 @@ def test_evaluator_on_gpu_matches_plain_rollout(dev, tmp_path, subprocess_mode):
     assert load_model(a2, "actor", str(tmp_path / "model.pth")) and float(a2.arena.data.abs().sum()) > 0
     holder = RunningMeanStd(shape=(8,), device=dev)
     assert load_model(holder, "obs_rms", str(tmp_path / "model.pth")) and torch.allclose(holder.mean, rms.mean)
+
+
+# --------------------------------------------------------------------------- SAC
+def _sac_cfg(extra=()):
+    from pql_amd.utils.cfg import load_cfg
+    return load_cfg(["algo=sac_algo", "task.name=Toy", "num_envs=64", "algo.batch_size=64", "algo.memory_size=400",
+                     "device=cuda:0", "sim_device=cuda:0", *extra])
+
+
+def test_sac_golden_trace(golden, dev):
+    """AgentSAC.update_once (HIP launch sequence) vs three iterations of the reference's AgentSAC.update_critic /
+    update_actor / soft_update on identical samples and rsample draws: losses, log_alpha, every parameter tensor."""
+    from pql_amd.algo.sac import AgentSAC
+    from pql_amd.envs.synthetic import create_task_env
+    from pql_amd.replay.simple_replay import ReplayBuffer
+    g = golden("sac"); O, A = 8, 2
+    cfg = _sac_cfg()
+    agent = AgentSAC(create_task_env(cfg), cfg)
+    agent.actor.load_state_dict(_sd(dd.mlp_state(O, 2 * A, 11)))
+    agent.critic.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 21))); agent.critic_target.arena.data.copy_(agent.critic.arena.data)
+    agent.obs_rms.mean, agent.obs_rms.var = T(g["sac_norm_mean"]).to(dev), T(g["sac_norm_var"]).to(dev)
+    memory = ReplayBuffer(400, (O,), A, device=dev)
+    memory.add_to_buffer(tuple(t.to(dev) for t in _fill(O, A, 300, 810)))
+    for s in range(3):
+        agent.update_once(memory, indices=T(g["sac_idx"][s]), eps_next=T(g["sac_eps"][2 * s]), eps_cur=T(g["sac_eps"][2 * s + 1]))
+        np.testing.assert_allclose(agent.closs[s % 5].item(), g["sac_closs"][s], rtol=2e-5)
+        np.testing.assert_allclose(agent.aloss[s % 5].item(), g["sac_aloss"][s], rtol=2e-5)
+        np.testing.assert_allclose(agent.log_alpha.item(), g["sac_log_alpha"][s], rtol=1e-5)
+        _check_module(agent.actor, g, f"sac_s{s}_a_")
+        _check_module(agent.critic, g, f"sac_s{s}_c_")
+        _check_module(agent.critic_target, g, f"sac_s{s}_t_")
+    np.testing.assert_allclose(agent.actor.layout.weight(agent.actor.arena.data, 0, 3).cpu().numpy(), g["sac_final_actor_last_w"],
+                               rtol=5e-5, atol=5e-7)
+    np.testing.assert_allclose(agent.critic.layout.weight(agent.critic.arena.data, 0, 3).cpu().numpy(), g["sac_final_q1_last_w"],
+                               rtol=5e-5, atol=5e-7)
+    assert abs(agent.get_alpha(scalar=True) - np.exp(g["sac_log_alpha"][2])) < 1e-6
+
+
+def test_sac_update_vs_oracle_allegro_shape(dev):
+    """AllegroHand shapes at batch 4096 with the BASELINE hidden sizes, two iterations vs the oracle's SACRef (learned and fixed
+    temperature)."""
+    from oracle import pql_ref_cpu as ref
+    from pql_amd.algo.sac import AgentSAC
+    from pql_amd.envs.synthetic import create_task_env
+    from pql_amd.replay.simple_replay import ReplayBuffer
+    O, A, B, rows = 88, 16, 4096, 6000
+    for fixed in (None, 0.2):
+        cfg = _sac_cfg(["task.name=AllegroHand", f"algo.batch_size={B}", "algo.memory_size=8000"] + ([f"algo.alpha={fixed}"] if fixed else []))
+        cfg.algo.hidden_layers = [512, 512, 256]
+        agent = AgentSAC(create_task_env(cfg), cfg)
+        ast, cst = dd.mlp_state(O, 2 * A, 11, hidden=(512, 512, 256)), dd.doubleq_state(O, A, 1, 21, hidden=(512, 512, 256))
+        agent.actor.load_state_dict(_sd(ast))
+        agent.critic.load_state_dict(_sd(cst)); agent.critic_target.arena.data.copy_(agent.critic.arena.data)
+        mean, var = T(dd.uniform((O,), 801, -0.5, 0.5)), T(dd.uniform((O,), 802, 0.5, 2.0))
+        agent.obs_rms.mean, agent.obs_rms.var = mean.to(dev), var.to(dev)
+        data = _fill(O, A, rows, 77)
+        memory = ReplayBuffer(8000, (O,), A, device=dev)
+        memory.add_to_buffer(tuple(t.to(dev) for t in data))
+        orc = ref.SACRef(O, A, ref.HyperRef(batch_size=B), 8000, ref.params_from_state(ast), ref.params_from_state(cst, "net_q1.net."),
+                         ref.params_from_state(cst, "net_q2.net."), alpha_lr=cfg.algo.alpha_lr, alpha=fixed)
+        orc.ring.insert(*data); orc.norm = (mean, var, 1e-4)
+        for s in range(2):
+            idx = T(dd.integers((B,), 40 + s, rows))
+            e1, e2 = T(dd.uniform((B, A), 50 + s, -2, 2)), T(dd.uniform((B, A), 60 + s, -2, 2))
+            cl, al_, _ = orc.update_once(idx, e1, e2)
+            agent.update_once(memory, indices=idx, eps_next=e1, eps_cur=e2)
+            np.testing.assert_allclose(agent.closs[s % 5].item(), cl, rtol=5e-5)
+            np.testing.assert_allclose(agent.aloss[s % 5].item(), al_, rtol=5e-5, atol=1e-6)
+        if fixed is None:
+            np.testing.assert_allclose(agent.log_alpha.item(), float(orc.log_alpha.detach()), rtol=1e-5)
+        else:
+            assert abs(agent.get_alpha(scalar=True) - fixed) < 1e-7
+        lay = agent.critic.layout
+        for n, net in enumerate((orc.q1, orc.q2)):
+            for l in range(lay.n_layers):
+                np.testing.assert_allclose(lay.weight(agent.critic.arena.data, n, l).cpu().numpy(), net[2 * l].detach().numpy(),
+                                           rtol=1e-5, atol=1e-5)
+        for l in range(agent.actor.layout.n_layers):
+            np.testing.assert_allclose(agent.actor.layout.weight(agent.actor.arena.data, 0, l).cpu().numpy(),
+                                       orc.actor[2 * l].detach().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_train_baselines_entry_point_sac(dev):
+    import importlib.util, os
+    from pql_amd.utils.cfg import load_cfg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_baselines", os.path.join(root, "scripts", "train_baselines.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    out = mod.main(load_cfg(["algo=sac_algo", "task.name=Toy", "num_envs=64", "algo.batch_size=256", "algo.memory_size=100000",
+                             "device=cuda:0", "sim_device=cuda:0", "max_step=4000", "algo.update_times=4"]))
+    assert out["global_steps"] > 4000 and np.isfinite(out["train/critic_loss"]) and np.isfinite(out["train/actor_loss"])
+    assert 0 < out["train/alpha"] < 1.0   # entropy above target at the start: the temperature decreases from 1

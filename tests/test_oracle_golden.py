@@ -251,3 +251,51 @@ def test_p_learner_trace(golden, distl):
         if not distl:
             _check_params(zip(_named(["net."], [p.actor]), p.actor), g, f"p_s{s}_p_")
     np.testing.assert_allclose(p.actor[-2].detach().numpy(), g[f"{tag}_final_last_w"], rtol=5e-5, atol=5e-7)
+
+
+# --------------------------------------------------------------------------- SAC
+@pytest.mark.parametrize("tag", ["kat_toy", "kat_allegro"])
+def test_squashed_gaussian_head(golden, tag):
+    """Oracle head vs the reference's TanhDiagGaussianMLPPolicy.get_actions_logprob with the rsample draw injected;
+    kat_allegro pushes log_std across the +-5 clamp and u into tanh saturation."""
+    g = golden("sac")
+    O, A, B = (int(v) for v in g[f"{tag}_meta"])
+    state = dd.mlp_state(O, 2 * A, 61)
+    if A > 2:
+        state["net.6.bias"] = state["net.6.bias"].copy()
+        state["net.6.bias"][A:] = np.linspace(-6.5, 6.5, A).astype(np.float32)
+    params = [p.requires_grad_(True) for p in ref.params_from_state(state)]
+    x, w = T(dd.uniform((B, O), 62, -2, 2)), T(dd.uniform((A,), 63, -1, 1))
+    a, logp = ref.squashed_gaussian_ref(params, x, T(g[f"{tag}_eps"]))
+    np.testing.assert_allclose(a.detach().numpy(), g[f"{tag}_act"], atol=1e-6)
+    np.testing.assert_allclose(logp.detach().numpy(), g[f"{tag}_logp"], rtol=1e-6, atol=1e-5)
+    loss = (0.3 * logp - (a * w).sum(-1, keepdim=True)).mean()
+    np.testing.assert_allclose(float(loss.detach()), float(g[f"{tag}_loss"]), rtol=1e-6)
+    gr = torch.autograd.grad(loss, params)
+    _grads_close(zip(_named(["net."], [params]), gr), g, f"{tag}_g_")
+    np.testing.assert_allclose(gr[-1].numpy(), g[f"{tag}_g_last_b"], rtol=2e-4, atol=2e-6)
+    with torch.no_grad():
+        mu = ref.mlp_forward_ref(params, x)[:, :A]
+    np.testing.assert_allclose(mu.tanh().numpy(), g[f"{tag}_mean_act"], atol=1e-6)
+
+
+def test_sac_trace(golden):
+    """SACRef vs three iterations of the reference's AgentSAC.update_critic / update_actor / soft_update."""
+    g = golden("sac"); O, A = 8, 2
+    hp = ref.HyperRef(batch_size=64)
+    st = dd.doubleq_state(O, A, 1, 21)
+    s = ref.SACRef(O, A, hp, 400, ref.params_from_state(dd.mlp_state(O, 2 * A, 11)), ref.params_from_state(st, "net_q1.net."),
+                   ref.params_from_state(st, "net_q2.net."), alpha_lr=0.005)
+    s.ring.insert(*_fill(O, A, 300, 810))
+    s.norm = (T(g["sac_norm_mean"]), T(g["sac_norm_var"]), 1e-4)
+    cn = _named(["net_q1.net.", "net_q2.net."], [s.q1, s.q2]); an = _named(["net."], [s.actor])
+    for i in range(3):
+        cl, al, _ = s.update_once(T(g["sac_idx"][i]), T(g["sac_eps"][2 * i]), T(g["sac_eps"][2 * i + 1]))
+        np.testing.assert_allclose(cl, g["sac_closs"][i], rtol=2e-5)
+        np.testing.assert_allclose(al, g["sac_aloss"][i], rtol=2e-5)
+        np.testing.assert_allclose(float(s.log_alpha.detach()), g["sac_log_alpha"][i], rtol=1e-5)
+        _check_params(zip(an, s.actor), g, f"sac_s{i}_a_")
+        _check_params(zip(cn, [*s.q1, *s.q2]), g, f"sac_s{i}_c_")
+        _check_params(zip(cn, [*s.t1, *s.t2]), g, f"sac_s{i}_t_")
+    np.testing.assert_allclose(s.actor[-2].detach().numpy(), g["sac_final_actor_last_w"], rtol=5e-5, atol=5e-7)
+    np.testing.assert_allclose(s.q1[-2].detach().numpy(), g["sac_final_q1_last_w"], rtol=5e-5, atol=5e-7)

@@ -59,6 +59,9 @@ def _install_shells():
         return lambda obj: obj
 
     mod("ray", remote=remote, get=lambda x: x)
+    sym = mod("bidex.utils.symmetry", load_symmetric_system=None)   # imported by pql/algo/ac_base.py:12, never called here
+    mod("bidex.utils", symmetry=sym)
+    mod("bidex")
 
 
 def _import_reference():
@@ -77,6 +80,8 @@ def _import_reference():
     from pql.utils.noise import add_normal_noise, add_mixed_normal_noise
     from pql.algo.pql_v_learner import PQLVLearner
     from pql.algo.pql_p_learner import PQLPLearner
+    from pql.models.mlp import TanhDiagGaussianMLPPolicy
+    from pql.algo.sac import AgentSAC
     return NS(**locals())
 
 
@@ -411,13 +416,102 @@ def gen_learners(R, out, steps=3):
     out["pd_final_last_w"] = p2.actor.state_dict()["net.6.weight"].numpy().copy()
 
 
+# --------------------------------------------------------------------------- SAC
+class _EpsCapture:
+    """Replace the standard-normal draw of torch.distributions.Normal.rsample by deterministic values and log them."""
+
+    def __init__(self, seed):
+        self.seed = seed; self.n = 0; self.draws = []
+
+    def __enter__(self):
+        import torch.distributions.normal as tdn
+        self._mod, self._orig = tdn, tdn._standard_normal
+
+        def std_normal(shape, dtype=None, device=None):
+            self.n += 1
+            d = dd.uniform(tuple(shape), self.seed + self.n, -2.0, 2.0)
+            self.draws.append(d)
+            return T(d)
+
+        tdn._standard_normal = std_normal
+        return self
+
+    def __exit__(self, *a):
+        self._mod._standard_normal = self._orig
+
+
+def gen_sac(R, out, steps=3):
+    from torch import nn
+    # known-answer vectors of the squashed-Gaussian head: actions, log-prob and parameter gradients of a scalar of both
+    for tag, O, A, B in (("kat_toy", 8, 2, 16), ("kat_allegro", 88, 16, 16)):
+        pol = R.TanhDiagGaussianMLPPolicy((O,), A)
+        state = dd.mlp_state(O, 2 * A, 61)
+        if A > 2:   # push some log_std outputs across the [-5, 5] clamp
+            state["net.6.bias"] = state["net.6.bias"].copy()
+            state["net.6.bias"][A:] = np.linspace(-6.5, 6.5, A).astype(np.float32)
+        load_state(pol, state)
+        x = T(dd.uniform((B, O), 62, -2, 2))
+        w = T(dd.uniform((A,), 63, -1, 1))
+        with _EpsCapture(6400) as cap:
+            a, _, logp = pol.get_actions_logprob(x)
+        loss = (0.3 * logp - (a * w).sum(-1, keepdim=True)).mean()
+        grads = torch.autograd.grad(loss, list(pol.parameters()))
+        out[f"{tag}_meta"] = np.array([O, A, B]); out[f"{tag}_eps"] = cap.draws[0]
+        out[f"{tag}_act"] = a.detach().numpy(); out[f"{tag}_logp"] = logp.detach().numpy(); out[f"{tag}_loss"] = np.array(float(loss.detach()))
+        for (k, _), g in zip(pol.named_parameters(), grads):
+            out[f"{tag}_g_{k}"] = dd.summarize(g.numpy())
+        out[f"{tag}_g_last_b"] = grads[-1].numpy().copy()
+        with torch.no_grad():
+            out[f"{tag}_mean_act"] = pol.get_actions(x, sample=False).numpy()
+
+    # update_net trace (sac.py:98-108): critic step, actor step, temperature step, Polyak; RNG = idx, eps_next, eps_cur per step
+    O, A, B = 8, 2, 64
+    norm = (dd.uniform((O,), 801, -0.5, 0.5), dd.uniform((O,), 802, 0.5, 2.0))
+    cfg = NS(info_track_keys=None, device="cpu",
+             algo=NS(batch_size=B, obs_norm=True, gamma=0.99, nstep=3, tau=0.05, max_grad_norm=0.5, alpha=None, alpha_lr=0.005,
+                     no_tgt_actor=True, update_times=1))
+    s = R.AgentSAC.__new__(R.AgentSAC)
+    s.cfg, s.obs_dim, s.action_dim, s.device = cfg, (O,), A, torch.device("cpu")
+    s.actor = R.TanhDiagGaussianMLPPolicy((O,), A); load_state(s.actor, dd.mlp_state(O, 2 * A, 11))
+    s.critic = R.DoubleQ((O,), A); load_state(s.critic, dd.doubleq_state(O, A, 1, 21))
+    s.critic_target = deepcopy(s.critic); s.actor_target = s.actor
+    s.actor_optimizer = torch.optim.AdamW(s.actor.parameters(), 5e-4)
+    s.critic_optimizer = torch.optim.AdamW(s.critic.parameters(), 5e-4)
+    s.log_alpha = nn.Parameter(torch.zeros(1)); s.alpha_optim = torch.optim.AdamW([s.log_alpha], lr=cfg.algo.alpha_lr)
+    s.target_entropy = -A
+    s.obs_rms = R.RunningMeanStd(shape=(O,), device="cpu"); s.obs_rms.mean, s.obs_rms.var = T(norm[0]), T(norm[1])
+    data = [T(d) for d in _fill_data(O, A, 300, 810)]
+    closs, aloss, alphas, idxs = [], [], [], []
+    with _EpsCapture(8500) as cap:
+        for st in range(steps):
+            idx = T(dd.integers((B,), 8600 + st, 300)); idxs.append(idx.numpy())
+            obs, act, rew, nobs, done = (d[idx] for d in data)
+            obs, nobs = s.obs_rms.normalize(obs), s.obs_rms.normalize(nobs)
+            cl, _ = s.update_critic(obs, act, rew, nobs, done)
+            al, _ = s.update_actor(obs)
+            R.soft_update(s.critic_target, s.critic, cfg.algo.tau)
+            closs.append(cl); aloss.append(al); alphas.append(float(s.log_alpha.detach()))
+            for k, p in s.actor.named_parameters():
+                out[f"sac_s{st}_a_{k}"] = dd.summarize(p.detach().numpy())
+            for k, p in s.critic.named_parameters():
+                out[f"sac_s{st}_c_{k}"] = dd.summarize(p.detach().numpy())
+            for k, p in s.critic_target.named_parameters():
+                out[f"sac_s{st}_t_{k}"] = dd.summarize(p.detach().numpy())
+    out["sac_closs"] = np.array(closs, np.float64); out["sac_aloss"] = np.array(aloss, np.float64)
+    out["sac_log_alpha"] = np.array(alphas, np.float64)
+    out["sac_idx"] = np.stack(idxs); out["sac_eps"] = np.stack(cap.draws)   # (2*steps, B, A): next, cur, next, cur, ...
+    out["sac_final_actor_last_w"] = s.actor.state_dict()["net.6.weight"].numpy().copy()
+    out["sac_final_q1_last_w"] = s.critic.state_dict()["net_q1.net.6.weight"].numpy().copy()
+    out["sac_norm_mean"] = norm[0]; out["sac_norm_var"] = norm[1]
+
+
 def main():
     torch.set_num_threads(1)
     torch.manual_seed(0)
     R = _import_reference()
     os.makedirs(OUT, exist_ok=True)
     for name, fn in (("replay", gen_ring), ("nstep", gen_nstep), ("models", gen_models), ("math", gen_math),
-                     ("learners", gen_learners)):
+                     ("learners", gen_learners), ("sac", gen_sac)):
         out = {}
         with torch.no_grad() if name in ("replay", "nstep") else contextlib.nullcontext():
             fn(R, out)
