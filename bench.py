@@ -232,6 +232,29 @@ def gather_ms(v, iters=50):
         return e0.elapsed_time(e1) / iters
 
 
+def free_running(actor, v, p, env, cfg, device, n=160):
+    """SURVEY 8(d) asks for the free-running rates as well (the reference with every sleep time forced to 0): each
+    component alone on the GPU, back to back, outside the timed region of `value`."""
+    out = {}
+
+    def rate(fn, reps, per_call=1.0):
+        for _ in range(4):
+            fn()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize(device)
+        return per_call * reps / (time.perf_counter() - t0)
+
+    out["v_grad_steps_per_s"] = rate(v.learn, n)
+    out["p_grad_steps_per_s"] = rate(p.learn, n)
+    out["env_steps_per_s"] = rate(lambda: actor.explore_env(env, int(cfg.algo.horizon_len), random=False), max(n // 4, 8),
+                                  per_call=float(cfg.num_envs) * int(cfg.algo.horizon_len))
+    out["note"] = "each component alone, back to back (no ratio control); not part of `value`"
+    return out
+
+
 def cpu_baseline(args, O, A, hidden):
     """The CPU oracle (port of the reference learner, pinned to the reference by tests/golden) on this host's
     cores, same schedule, bounded sample."""
@@ -393,6 +416,9 @@ def main():
                                    "traffic": traffic.get("gather_per_launch_bytes"), "algorithmic_bytes": alg_bytes,
                                    "us_per_launch": gms * 1e3, "record_bytes": rec_ld * 4}
         note("roofline sections measured")
+        if world == 1 and not args.v_only:
+            line["free_running"] = free_running(actor, v, p, env, cfg, device)
+            note("free-running rates measured")
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, O, A, hidden)
             note("cpu baseline done")

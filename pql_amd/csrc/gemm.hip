@@ -49,6 +49,8 @@ struct GemmP {
   float noise_std, noise_clip;
 };
 
+#include "narrow.h"
+
 #define KT_MAX 32   // reduction elements per LDS stage (template parameter KT: 32 or 16)
 #ifndef PQLK_KT
 #define PQLK_KT 16   // 16: half the LDS per block -> a third block per CU; +3 % on the streamed learner step vs 32
@@ -663,6 +665,8 @@ extern "C" int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const 
       q.draw = p.aux; q.noise_std = noise_std; q.noise_clip = noise_clip;
       q.C2 = p.C2; q.ldc2 = p.ldc2;
       rc = launch_skinny_fwd(q, d->n_nets, pqlk_s(stream));
+    } else if (l == L - 1 && narrow_fwd_ok(p)) {   // 5..64 outputs (action heads, C51 logits): one wave per 32-row tile
+      rc = launch_fwd_narrow(p, d->n_nets, pqlk_s(stream));
     } else {
       rc = launch_auto<MODE_FWD>(p, d->n_nets, pqlk_s(stream));
     }
