@@ -801,7 +801,8 @@ extern "C" int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const
       } else {
         p.epi = EPI_NONE;
       }
-      rc = launch_auto<MODE_DX>(p, 1, st);
+      if (dx_slice_ok(p)) rc = launch_dx_slice(p, st);   // narrow slice: split-reduction MFMA kernel (narrow.h)
+      else rc = launch_auto<MODE_DX>(p, 1, st);
       if (rc) return rc;
     }
   }

@@ -3,15 +3,16 @@
 // 16-wide head, launches only M/64 = 128 blocks at batch 8192 and pays a full LDS pipeline for 16 KB of weights.  Here
 // one wave owns a 32-row tile and NT 32-column output tiles; BOTH operands come straight from global memory as the
 // k-contiguous float4 quads the MFMA fragments want (x row r / weight row n, reduction index 8 k8 + 4 h + t): the weight
-// block is a few KB and lives in L1/L2, no LDS, no barrier.  Same k-order and operand roles as k_gemm, so results are
-// bitwise equal to the generic path.
+// block is a few KB and lives in L1/L2, no LDS, no barrier.
 #pragma once
 #include "pqlk_common.h"
 
-template <int NT, int EPI>
+template <int NT, int EPI, int D>
 __global__ __launch_bounds__(64) void k_fwd_narrow(GemmP p) {
   typedef float acc_t __attribute__((ext_vector_type(16)));
-  constexpr int D = 4;   // ring depth (reduction steps of 8)
+  // D = ring depth in reduction steps of 8 (K8 is a multiple of D: straight-line refills, counted waits).  One wave per SIMD
+  // and nothing else to hide latency behind: the loop is bound by (memory latency) / D per step, so the launcher picks the
+  // deepest ring that divides K8 and fits the registers.
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   const int g = blockIdx.y;
   const int m0 = blockIdx.x * 32;
@@ -21,19 +22,28 @@ __global__ __launch_bounds__(64) void k_fwd_narrow(GemmP p) {
 #pragma unroll
   for (int j = 0; j < NT; ++j)   // weight rows past N are clamped: their output columns are never stored
     wp[j] = reinterpret_cast<const float4*>(p.B + (long long)g * p.sB + (long long)min(32 * j + r, p.N - 1) * p.ldb) + h;
-  acc_t acc[NT];
+  // A wave is alone on its SIMD here, and a dependent v_mfma_f32_32x32x2 chain issues only every ~125 cycles (measured:
+  // 128 chained MFMAs = 7.7 us) against 64 for independent ones: each output tile therefore accumulates into NA
+  // accumulators by reduction-step parity (step s -> s mod NA), summed pairwise at the end.  Deterministic; the
+  // summation order differs from k_gemm's single chain by reassociation only.
+  constexpr int NA = NT == 1 ? 4 : 2;
+  acc_t acc[NT][NA];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[j][a][e] = 0.f;
   const int K8 = p.K >> 3;   // K is a multiple of 32
   float4 xq[D], wq[D][NT];
 #pragma unroll
   for (int s = 0; s < D; ++s) {
-    xq[s] = xp[2 * s];
+    const int ks = min(s, K8 - 1);
+    xq[s] = xp[2 * ks];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) wq[s][j] = wp[j][2 * s];
+    for (int j = 0; j < NT; ++j) wq[s][j] = wp[j][2 * ks];
   }
+  __builtin_amdgcn_sched_barrier(0);
   for (int k8 = 0; k8 < K8; k8 += D) {
 #pragma unroll
     for (int s = 0; s < D; ++s) {
@@ -43,12 +53,13 @@ __global__ __launch_bounds__(64) void k_fwd_narrow(GemmP p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const float bv = t == 0 ? wq[s][j].x : t == 1 ? wq[s][j].y : t == 2 ? wq[s][j].z : wq[s][j].w;
-          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av[t], acc[j], 0, 0, 0);
+          acc[j][s % NA] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv, av[t], acc[j][s % NA], 0, 0, 0);
         }
-      const int kn = min(k8 + s + D, K8 - 1);   // clamped, unconditional refill (counted waits)
+      const int kn = min(k8 + s + D, K8 - 1);   // clamped, unconditional refill
       xq[s] = xp[2 * kn];
 #pragma unroll
       for (int j = 0; j < NT; ++j) wq[s][j] = wp[j][2 * kn];
+      __builtin_amdgcn_sched_barrier(0);   // keep the refill HERE: hipcc otherwise sinks every load to just before its use
     }
   }
   // epilogue: lane (r, h) owns row m0 + r, columns 32 j + 8 q + 4 h + {0..3}
@@ -57,6 +68,51 @@ __global__ __launch_bounds__(64) void k_fwd_narrow(GemmP p) {
   float* C = p.C + (long long)g * p.sC;
   const float* bias = p.bias ? p.bias + (long long)g * p.sBias : nullptr;
   const float* aux = p.aux ? p.aux + (long long)g * p.sAux : nullptr;
+  float* C2 = (p.C2 && g == 0) ? p.C2 : nullptr;
+  // 16-B path: every quad lies inside [0, N) or inside the pad, and all four streams are 16-B aligned.  All loads of the
+  // epilogue are issued before any of its math (a wave alone on its SIMD has nothing else to hide their latency behind).
+  auto al16 = [](const void* q) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0; };
+  const bool vec = (p.N & 3) == 0 && (p.ncols_store & 3) == 0 && bias && al16(bias) && al16(C) && (!aux || al16(aux)) &&
+                   (!C2 || (al16(C2) && (p.ldc2 & 3) == 0));
+  if (vec) {
+    float4 b4[NT][4], n4[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = min(32 * j + 8 * q + 4 * h, p.N - 4);
+        b4[j][q] = *reinterpret_cast<const float4*>(bias + c);
+        n4[j][q] = (EPI == EPI_TANH_NOISE) ? *reinterpret_cast<const float4*>(aux + (long long)orow * p.N + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 32 * j + 8 * q + 4 * h;
+        if (c >= p.ncols_store) continue;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};   // pad quad
+        if (c < p.N) {
+          const float bb[4] = {b4[j][q].x, b4[j][q].y, b4[j][q].z, b4[j][q].w};
+          const float nn[4] = {n4[j][q].x, n4[j][q].y, n4[j][q].z, n4[j][q].w};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int e = 4 * q + u;
+            const float dot = NA == 4 ? (acc[j][0][e] + acc[j][1][e]) + (acc[j][2 % NA][e] + acc[j][3 % NA][e]) : acc[j][0][e] + acc[j][1][e];
+            float x = dot + bb[u];
+            if (EPI == EPI_TANH) x = tanhf(x);
+            else if (EPI == EPI_TANH_NOISE) {
+              x = tanhf(x);
+              const float nz = fminf(fmaxf(p.noise_std * nn[u], -p.noise_clip), p.noise_clip);
+              x = fminf(fmaxf(x + nz, -1.f), 1.f);
+            }
+            v[u] = x;
+          }
+          if (C2) *reinterpret_cast<float4*>(C2 + (long long)orow * p.ldc2 + c) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        *reinterpret_cast<float4*>(C + (long long)orow * p.ldc + c) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -67,7 +123,9 @@ __global__ __launch_bounds__(64) void k_fwd_narrow(GemmP p) {
         if (c >= p.ncols_store) continue;
         float x = 0.f;   // pad column
         if (c < p.N) {
-          x = acc[j][4 * q + u] + (bias ? bias[c] : 0.f);
+          const int e = 4 * q + u;
+          const float dot = NA == 4 ? (acc[j][0][e] + acc[j][1][e]) + (acc[j][2 % NA][e] + acc[j][3 % NA][e]) : acc[j][0][e] + acc[j][1][e];
+          x = dot + (bias ? bias[c] : 0.f);
           if (EPI == EPI_TANH) x = tanhf(x);
           else if (EPI == EPI_TANH_NOISE) {
             x = tanhf(x);
@@ -75,7 +133,7 @@ __global__ __launch_bounds__(64) void k_fwd_narrow(GemmP p) {
             nz = fminf(fmaxf(nz, -p.noise_clip), p.noise_clip);
             x = fminf(fmaxf(x + nz, -1.f), 1.f);
           }
-          if (p.C2 && g == 0) p.C2[(long long)orow * p.ldc2 + c] = x;
+          if (C2) C2[(long long)orow * p.ldc2 + c] = x;
         }
         C[(long long)orow * p.ldc + c] = x;
       }
@@ -86,8 +144,15 @@ static bool narrow_fwd_ok(const GemmP& p) { return p.N <= 64 && p.K >= 32 && (p.
 template <int EPI>
 static int launch_fwd_narrow_e(const GemmP& p, int groups, hipStream_t st) {
   const dim3 grid((unsigned)((p.M + 31) / 32), (unsigned)groups), block(64);
-  if (p.N <= 32) hipLaunchKernelGGL((k_fwd_narrow<1, EPI>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((k_fwd_narrow<2, EPI>), grid, block, 0, st, p);
+  const int K8 = p.K >> 3;   // multiple of 4
+  if (p.N <= 32) {
+    if (K8 % 16 == 0) hipLaunchKernelGGL((k_fwd_narrow<1, EPI, 16>), grid, block, 0, st, p);
+    else if (K8 % 8 == 0) hipLaunchKernelGGL((k_fwd_narrow<1, EPI, 8>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((k_fwd_narrow<1, EPI, 4>), grid, block, 0, st, p);
+  } else {
+    if (K8 % 8 == 0) hipLaunchKernelGGL((k_fwd_narrow<2, EPI, 8>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((k_fwd_narrow<2, EPI, 4>), grid, block, 0, st, p);
+  }
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }
@@ -99,4 +164,137 @@ static int launch_fwd_narrow(const GemmP& p, int groups, hipStream_t st) {
     case EPI_TANH_NOISE: return launch_fwd_narrow_e<EPI_TANH_NOISE>(p, groups, st);
     default: return PQLK_E_UNSUPPORTED;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Input-gradient SLICE of the first layer: dX[m, col0 + c] * (1 - a[m, c]^2), c < ncol <= 32, summed over the nets --
+// the DPG chain from the critic into the actor's tanh (pql_p_learner.py:55-58).  Output is 16-21 columns wide against a
+// reduction of n_nets x 512, so k_gemm's 64x64 tile leaves 3/4 of its MFMAs and half of the CUs idle (55 us at batch
+// 8192).  Here a block owns one 32-row tile and its 4 waves each take a quarter of the (net, k) reduction range; the
+// four partial tiles are summed through LDS in wave order (deterministic).  Weight-side fragments need W[k][col0 + c]
+// with k fastest, i.e. the transpose of the row-major slice: each wave stages ITS quarter transposed into LDS once
+// (16-B global loads when col0 is 16-B aligned), batch-side fragments (dY rows) come straight from global.
+
+template <int D>   // ring depth; K8 % D == 0
+__global__ __launch_bounds__(256) void k_dx_slice(GemmP p) {
+  typedef float acc_t __attribute__((ext_vector_type(16)));
+  extern __shared__ __attribute__((aligned(16))) float dxs_lds[];   // 4 waves x 32 columns x (kq + 4)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 32;
+  const int ktot = p.groups * p.K;          // p.K = hidden width (multiple of 32)
+  const int kq = ktot >> 2;                 // reduction elements of this wave; multiple of 8
+  const int kbeg = wave * kq;
+  const int ldw = kq + 4;                   // LDS row stride: conflict-free b128 reads
+  float* wt = dxs_lds + wave * 32 * ldw;    // wt[c][k - kbeg]
+  {  // stage W[k][col0 .. col0 + 32) transposed; columns past ncol are zero
+    const bool vec = (p.col0 & 3) == 0 && (p.ldb & 3) == 0;
+    if (vec) {
+      // kq * 8 float4 (8 per reduction row) over 64 lanes, 8 loads in flight per lane: a load -> LDS-store loop with one
+      // load in flight costs a full L2 latency per iteration (this staging alone was ~20 us that way)
+      for (int i0 = lane; i0 < kq * 8; i0 += 64 * 8) {
+        float4 v[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const int i = i0 + 64 * b;
+          const int kk = i >> 3, c4 = i & 7;
+          const int kg = kbeg + min(kk, kq - 1), g = kg / p.K, k = kg - g * p.K;
+          v[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (i < kq * 8 && 4 * c4 < p.ncol)
+            v[b] = *reinterpret_cast<const float4*>(p.B + (long long)g * p.sB + (long long)k * p.ldb + p.col0 + 4 * c4);
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const int i = i0 + 64 * b;
+          if (i < kq * 8) {
+            const int kk = i >> 3, c4 = i & 7;
+            const float e[4] = {v[b].x, v[b].y, v[b].z, v[b].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wt[(4 * c4 + u) * ldw + kk] = (4 * c4 + u < p.ncol) ? e[u] : 0.f;
+          }
+        }
+      }
+    } else {
+      for (int i = lane; i < kq * 32; i += 64) {
+        const int kk = i >> 5, c = i & 31;
+        const int kg = kbeg + kk, g = kg / p.K, k = kg - g * p.K;
+        wt[c * ldw + kk] = c < p.ncol ? p.B[(long long)g * p.sB + (long long)k * p.ldb + p.col0 + c] : 0.f;
+      }
+    }
+  }
+  // the wave reads only what it staged itself: no block barrier needed before the loop (LDS ops of a wave are in order)
+  const int row = min(m0 + r, p.M - 1);
+  const int g0 = kbeg / p.K, koff = kbeg - g0 * p.K;   // a wave's quarter lies inside one net when n_nets divides 4
+  const float4* yp = reinterpret_cast<const float4*>(p.A + (long long)g0 * p.sA + (long long)row * p.lda + koff) + h;
+  acc_t acc4[4];   // by reduction-step parity: four independent MFMA chains (see k_fwd_narrow)
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc4[a][e] = 0.f;
+  const int K8 = kq >> 3;
+  float4 yq[D];   // one wave per SIMD: latency-bound, so a deep ring (see k_fwd_narrow)
+#pragma unroll
+  for (int s = 0; s < D; ++s) yq[s] = yp[2 * min(s, K8 - 1)];
+  __builtin_amdgcn_sched_barrier(0);
+  for (int k8 = 0; k8 < K8; k8 += D) {
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      const float4 w4 = *reinterpret_cast<const float4*>(&wt[r * ldw + 8 * (k8 + s) + 4 * h]);
+      acc_t& acc = acc4[s & 3];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, yq[s].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, yq[s].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, yq[s].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, yq[s].w, acc, 0, 0, 0);
+      yq[s] = yp[2 * min(k8 + s + D, K8 - 1)];
+      __builtin_amdgcn_sched_barrier(0);   // keep the refill here (see k_fwd_narrow)
+    }
+  }
+  // partial tiles -> LDS (reusing the staging area after everyone is done with it), summed in wave order by wave 0
+  __syncthreads();
+  float* red = dxs_lds;   // [wave][reg][lane]
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = (acc4[0][e] + acc4[1][e]) + (acc4[2][e] + acc4[3][e]);
+  __syncthreads();
+  if (wave != 0) return;
+  const int orow = m0 + r;
+  if (orow >= p.M) return;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const float s = ((red[e * 64 + lane] + red[(16 + e) * 64 + lane]) + red[(32 + e) * 64 + lane]) + red[(48 + e) * 64 + lane];
+    const int c = 8 * (e >> 2) + 4 * h + (e & 3);
+    if (c < p.ncol) {
+      const float a = p.aux[(long long)orow * p.ldaux + c];
+      p.C[(long long)orow * p.ldc + c] = s * (1.f - a * a);
+    }
+  }
+}
+
+static size_t dx_slice_lds(const GemmP& p) {
+  const size_t stage = (size_t)4 * 32 * (p.groups * p.K / 4 + 4) * sizeof(float);
+  return stage > 16384 ? stage : 16384;   // the staging area doubles as the 4 x 16 x 64-float reduction buffer
+}
+
+static bool dx_slice_ok(const GemmP& p) {
+  return p.epi == EPI_DTANH_SLICE && p.zsum && p.ncol <= 32 && (p.K & 31) == 0 && (4 % p.groups) == 0 && (p.lda & 3) == 0 &&
+         dx_slice_lds(p) <= 160 * 1024;
+}
+
+static int launch_dx_slice(const GemmP& p, hipStream_t st) {
+  const size_t shmem = dx_slice_lds(p);
+  static bool attr_set = false;
+  if (!attr_set) {
+    for (const void* k : {reinterpret_cast<const void*>(&k_dx_slice<16>), reinterpret_cast<const void*>(&k_dx_slice<4>),
+                          reinterpret_cast<const void*>(&k_dx_slice<1>)}) {
+      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return -(int)e;
+    }
+    attr_set = true;
+  }
+  const int K8 = p.groups * p.K / 32;   // reduction steps of 8 per wave
+  const dim3 grid((unsigned)((p.M + 31) / 32)), block(256);
+  if (K8 % 16 == 0) hipLaunchKernelGGL(k_dx_slice<16>, grid, block, shmem, st, p);
+  else if (K8 % 4 == 0) hipLaunchKernelGGL(k_dx_slice<4>, grid, block, shmem, st, p);
+  else hipLaunchKernelGGL(k_dx_slice<1>, grid, block, shmem, st, p);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
 }

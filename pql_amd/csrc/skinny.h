@@ -131,16 +131,21 @@ __global__ __launch_bounds__(256) void k_skinny_dx(SkinnyP p) {
 }
 
 // ---------------------------------------------------------------------------------------------- dW, db (split-batch slabs)
-// grid = (ceil(K/64), splits, groups); block = 16 column-lanes (float4 = 64 columns) x 16 row-lanes.  Each thread
-// streams its rows with 4 independent 16-B loads in flight; the 16 row-lanes are folded through LDS in fixed order.
-#define SKDW_ROWS 128
+// grid = (ceil(K / (4 CLS)), splits, groups); block = CLS column-lanes (one float4 = 4 columns each) x RLS = 256 / CLS
+// row-lanes.  Each thread streams its rows with 4 independent 16-B loads in flight; the row-lanes are folded through LDS
+// in fixed order.  CLS = 16 (64 columns per block) when that already gives every CU a block; CLS = 4 (16 columns per
+// block, 4x the blocks) otherwise -- the 256 -> 16 action head at 16 splits is 64 blocks at CLS = 16 (47 us).
+template <int CLS>
 __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
-  __shared__ float dy_lds[SKDW_ROWS][SKINNY_MAX_N + 1];
-  __shared__ __attribute__((aligned(16))) float red[16][16][4];
-  __shared__ float redb[16][SKINNY_MAX_N];
+  constexpr int RLS = 256 / CLS;
+  constexpr int ROWS = RLS * 8 <= 256 ? RLS * 8 : 256;   // rows per chunk: 8 per thread (CLS = 16) or 4 (CLS = 4)
+  constexpr int CSH = CLS == 16 ? 4 : 2;                 // log2(CLS)
+  static_assert(CLS == 16 || CLS == 4, "column-lane count");
+  __shared__ float dy_lds[ROWS][SKINNY_MAX_N + 1];
+  __shared__ __attribute__((aligned(16))) float red[8][RLS][CLS][4];   // 32 KB
   const int g = blockIdx.z, split = blockIdx.y;
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int col = blockIdx.x * 64 + 4 * cl;
+  const int cl = threadIdx.x & (CLS - 1), rl = threadIdx.x >> CSH;
+  const int col = blockIdx.x * (4 * CLS) + 4 * cl;
   const float* X = p.X + (long long)g * p.sX;
   const float* dY = p.dY + (long long)g * p.sY;
   const int m_beg = split * p.rows_per_split;
@@ -148,28 +153,28 @@ __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
   float4 acc[SKINNY_MAX_N];
 #pragma unroll
   for (int n = 0; n < SKINNY_MAX_N; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
-  float dbacc = 0.f;
+  float dbacc = 0.f;   // block column 0 only: lanes tid < N each own one bias column over this block's rows
   const bool col_ok = col < p.K;
-  for (int m0 = m_beg; m0 < m_end; m0 += SKDW_ROWS) {
+  for (int m0 = m_beg; m0 < m_end; m0 += ROWS) {
     __syncthreads();
-    for (int i = threadIdx.x; i < SKDW_ROWS * p.N; i += 256) {
+    for (int i = threadIdx.x; i < ROWS * p.N; i += 256) {
       const int r = i / p.N, n = i % p.N;
       dy_lds[r][n] = (m0 + r < m_end) ? dY[(long long)(m0 + r) * p.ldy + n] : 0.f;
     }
     __syncthreads();
-    // rows rl, rl+16, ... of this 128-row chunk: 8 rows per thread, loads issued 4 at a time
+    // rows rl, rl + RLS, ... of this chunk, loads issued 4 at a time
 #pragma unroll
-    for (int u = 0; u < SKDW_ROWS / 16; u += 4) {
+    for (int u = 0; u < ROWS / RLS; u += 4) {
       float4 hv[4];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const int r = rl + 16 * (u + v);
+        const int r = rl + RLS * (u + v);
         hv[v] = (col_ok && m0 + r < m_end) ? *reinterpret_cast<const float4*>(X + (long long)(m0 + r) * p.ldx + col)
                                           : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-        const int r = rl + 16 * (u + v);
+        const int r = rl + RLS * (u + v);
 #pragma unroll
         for (int n = 0; n < SKINNY_MAX_N; ++n) {
           if (n < p.N) {
@@ -177,39 +182,46 @@ __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
             acc[n].x += d * hv[v].x; acc[n].y += d * hv[v].y; acc[n].z += d * hv[v].z; acc[n].w += d * hv[v].w;
           }
         }
-        if (blockIdx.x == 0 && cl < p.N) dbacc += dy_lds[r][cl];
       }
     }
+    if (blockIdx.x == 0 && (int)threadIdx.x < p.N)   // bias gradient: one thread per output, rows in order
+      for (int r = 0; r < ROWS; ++r) dbacc += dy_lds[r][threadIdx.x];
   }
   float* dW = p.dW + (long long)g * p.sW + (long long)split * p.sSplit;
-  // compile-time n everywhere: a runtime index would push acc[] to scratch memory (7x slower)
+  // Fold the RLS row-lanes: eight outputs n at a time go to LDS, then ALL threads reduce -- P = 256 / (8 CLS) threads per
+  // (n, column-lane) output, each summing a contiguous run of row-lanes, combined by a fixed shuffle tree.  (One
+  // thread per column-lane walking all RLS partials for each n in turn was 1024 dependent LDS reads: 30 of the 47 us.)
+  // Compile-time n everywhere: a runtime index would push acc[] to scratch memory (7x slower).
+  constexpr int P = 256 / (8 * CLS);
+  const int out = threadIdx.x / P, part = threadIdx.x % P;
+  const int onn = out / CLS, oc = out % CLS;
+  const int ocol = blockIdx.x * (4 * CLS) + 4 * oc;
 #pragma unroll
-  for (int n = 0; n < SKINNY_MAX_N; ++n) {
-    if (n < p.N) {  // block-uniform
+  for (int half = 0; half < SKINNY_MAX_N / 8; ++half) {
+    if (8 * half < p.N) {  // block-uniform
       __syncthreads();
-      *reinterpret_cast<float4*>(&red[rl][cl][0]) = acc[n];
-      __syncthreads();
-      if (rl == 0 && col_ok) {
-        float4 s = *reinterpret_cast<float4*>(&red[0][cl][0]);
 #pragma unroll
-        for (int k = 1; k < 16; ++k) {
-          const float4 t = *reinterpret_cast<float4*>(&red[k][cl][0]);
+      for (int nn = 0; nn < 8; ++nn)
+        if (8 * half + nn < p.N) *reinterpret_cast<float4*>(&red[nn][rl][cl][0]) = acc[8 * half + nn];
+      __syncthreads();
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (8 * half + onn < p.N) {
+#pragma unroll 8
+        for (int k = part * (RLS / P); k < (part + 1) * (RLS / P); ++k) {
+          const float4 t = *reinterpret_cast<float4*>(&red[onn][k][oc][0]);
           s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
-        *reinterpret_cast<float4*>(dW + (long long)n * p.ldk + col) = s;
       }
+#pragma unroll
+      for (int o = 1; o < P; o <<= 1) {   // the P partial sums sit in adjacent lanes
+        s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+      }
+      if (part == 0 && 8 * half + onn < p.N && ocol < p.K) *reinterpret_cast<float4*>(dW + (long long)(8 * half + onn) * p.ldk + ocol) = s;
     }
   }
-  if (blockIdx.x == 0) {
-    if (cl < SKINNY_MAX_N) redb[rl][cl] = dbacc;
-    __syncthreads();
-    if (threadIdx.x < p.ldc) {  // ldc = pqlk_ld(N) <= 32: zero the bias pad
-      float* dB = p.dB + (long long)g * p.sBias + (long long)split * p.sSplit;
-      float s = 0.f;
-      if ((int)threadIdx.x < p.N)
-        for (int k = 0; k < 16; ++k) s += redb[k][threadIdx.x];
-      dB[threadIdx.x] = s;
-    }
+  if (blockIdx.x == 0 && (int)threadIdx.x < p.ldc) {  // ldc = pqlk_ld(N) <= 32: zero the bias pad
+    float* dB = p.dB + (long long)g * p.sBias + (long long)split * p.sSplit;
+    dB[threadIdx.x] = (int)threadIdx.x < p.N ? dbacc : 0.f;
   }
 }
 
@@ -251,7 +263,9 @@ static int launch_skinny_dx(const SkinnyP& p, int groups, hipStream_t st) {
 }
 
 static int launch_skinny_dw(const SkinnyP& p, int groups, hipStream_t st) {
-  hipLaunchKernelGGL(k_skinny_dw, dim3((p.K + 63) / 64, p.splits, groups), dim3(256), 0, st, p);
+  const int wide = ((p.K + 63) / 64) * p.splits * groups;
+  if (wide >= 256) hipLaunchKernelGGL(k_skinny_dw<16>, dim3((p.K + 63) / 64, p.splits, groups), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(k_skinny_dw<4>, dim3((p.K + 15) / 16, p.splits, groups), dim3(256), 0, st, p);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }

@@ -573,3 +573,39 @@ def test_squashed_gaussian_head_golden(golden, dev, tag):
             np.testing.assert_allclose(dd.summarize(view.cpu().numpy()), g[f"{tag}_g_net.{2 * l}.{kind}"], rtol=2e-4, atol=2e-6,
                                        err_msg=f"{kind} {l}")
     np.testing.assert_allclose(lay.bias(grads, 0, lay.n_layers - 1).cpu().numpy(), g[f"{tag}_g_last_b"], rtol=2e-4, atol=2e-6)
+
+
+# --------------------------------------------------------------------------- narrow kernels (narrow.h)
+@pytest.mark.parametrize("O,A,hidden,B", [(88, 16, [512, 512, 256], 8192), (211, 20, [512, 256, 128], 1000), (8, 2, [64, 32], 77),
+                                          (108, 21, [256, 256], 333)])
+def test_dx_slice_kernel_equals_full_input_gradient(dev, O, A, hidden, B):
+    """The DPG slice kernel (split-reduction MFMA, action columns only, tanh' fused) vs the generic path: the full input
+    gradient from the same call with dx_tanh_of = NULL, sliced and multiplied by (1 - a^2) in torch.  The two differ only
+    in summation order (4 partial sums vs one chain)."""
+    from pql_amd import _lib as L
+    from pql_amd.models.mlp import ArenaLayout, mlp_forward_raw
+    lay = ArenaLayout([O + A, *hidden, 1], 2)
+    arena = torch.zeros(lay.total, device=dev)
+    for n in range(2):
+        for l in range(lay.n_layers):
+            bound = 1.0 / np.sqrt(lay.dims[l])
+            lay.weight(arena, n, l).copy_(T(dd.uniform((lay.dims[l + 1], lay.dims[l]), 100 * n + l, -bound, bound)))
+            lay.bias(arena, n, l).copy_(T(dd.uniform((lay.dims[l + 1],), 100 * n + l + 50, -bound, bound)))
+    x = torch.zeros((B, lay.ld_in), device=dev)
+    x[:, : O + A] = T(dd.uniform((B, O + A), 7, -1, 1)).to(dev)
+    acts = mlp_forward_raw(lay, arena, x, L.ACT_NONE)
+    dy = torch.zeros((2, B, lay.ld_out), device=dev)
+    dy[:, :, 0] = T(dd.uniform((2, B), 9, -1, 1)).to(dev)
+    a = torch.tanh(T(dd.uniform((B, A), 11, -2, 2))).to(dev).contiguous()
+    ws = torch.empty(lay.bwd_ws_floats(B, 1), device=dev)
+    full = torch.zeros((B, lay.ld_in), device=dev)
+    L.check(L.lib.pqlk_mlp_backward(C.byref(lay.desc), L.ptr(arena), L.ptr(x), lay.ld_in, B, L.ptr(acts), L.ptr(dy), None, 1, L.ptr(full),
+                                    lay.ld_in, 0, 0, None, 0, L.ptr(ws), ws.numel(), L.stream(dev)))
+    ld_a = L.ld(A)
+    sl = torch.full((B, ld_a), 3.0, device=dev)
+    L.check(L.lib.pqlk_mlp_backward(C.byref(lay.desc), L.ptr(arena), L.ptr(x), lay.ld_in, B, L.ptr(acts), L.ptr(dy), None, 1, L.ptr(sl),
+                                    ld_a, O, A, L.ptr(a), A, L.ptr(ws), ws.numel(), L.stream(dev)))
+    want = full[:, O:O + A] * (1 - a * a)
+    scale = float(want.abs().max())
+    np.testing.assert_allclose(sl[:, :A].cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-6 * scale)
+    assert torch.all(sl[:, A:] == 3.0)   # only the slice columns are written
