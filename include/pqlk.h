@@ -294,6 +294,27 @@ int pqlk_sac_alpha_terms(const float* logp, int64_t b, const float* log_alpha, f
                          const int32_t* slot_dev, int32_t ring_len, pqlk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * BatchNorm1d + ELU blocks of the CrossQ critic (reference pql/models/mlp.py:15-24,224-241,
+ * pql/algo/crossQ.py:144-166).  The Linear layers run as one-layer PqlMlpDesc calls of pqlk_mlp_forward / _backward; the
+ * batch statistics come from pqlk_batch_moments (mean, UNBIASED variance over the m rows).
+ *
+ * Forward: y = ELU(z * w + b), w = gamma * invstd, b = beta - mean * w, invstd = 1/sqrt(var + eps) (ATen's order).
+ * training != 0: mean / var = the batch statistics (biased variance = var_unbiased * (m-1)/m) and, when running_mean is
+ * not NULL, running_{mean,var} <- (1 - momentum) * running + momentum * (mean, var_unbiased) (torch: momentum 0.1,
+ * eps 1e-5).  training == 0: the running statistics normalise and nothing is updated.  z, y: (m, ld), cols <= ld. */
+int pqlk_bn_elu_forward(const float* z, int64_t ld, int64_t m, int32_t cols, const float* mean, const float* var_unbiased,
+                        const float* gamma, const float* beta, float eps, int32_t training, float momentum,
+                        float* running_mean, float* running_var, float* y, pqlk_stream_t stream);
+
+/* Backward of the training-mode block: dy = d loss / d y (post-ELU), y and z as stored by the forward ->
+ * dz = gamma * invstd * (g - mean_rows(g) - xhat * mean_rows(g * xhat)), g = dy * ELU'(pre) with ELU' taken from y,
+ * dgamma = sum_rows(g * xhat), dbeta = sum_rows(g) (either may be NULL).  dz may alias dy.
+ * scratch: >= 128 * cols floats (64 row chunks x 2 column sums, folded in chunk order: deterministic). */
+int pqlk_bn_elu_backward(const float* dy, const float* y, const float* z, int64_t ld, int64_t m, int32_t cols,
+                         const float* mean, const float* var_unbiased, const float* gamma, float eps, float* dz,
+                         float* dgamma, float* dbeta, float* scratch, pqlk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Synthetic vectorised environment step (the Isaac-Gym stand-in of BASELINE.json; not a reference component).
  * Counter-based: outputs depend only on (seed, env_offset + env, t, column), so shards of the env axis reproduce
  * slices of the global env.  next_obs ~ N(0,1) (N, obs_dim); reward = N(0,1) - 0.1 mean(action^2) (N);

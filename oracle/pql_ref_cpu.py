@@ -538,3 +538,63 @@ class SACRef:
             self.alpha_opt.apply(list(torch.autograd.grad(alpha_loss, [self.log_alpha])), hp.max_grad_norm)
         polyak_ref([*self.t1, *self.t2], [p.detach() for p in cp], hp.tau)
         return float(closs.detach()), float(aloss.detach()), None if alpha_loss is None else float(alpha_loss.detach())
+
+
+# ------------------------------------------------------------------------------------------------ CrossQ
+def bn_mlp_forward_ref(lin, bn, stats, x, training=True, momentum=0.1, eps=1e-5):
+    """create_simple_mlp(use_batchnorm=True) (pql/models/mlp.py:15-24): Linear -> BatchNorm1d -> ELU per hidden layer.
+    lin = [W0, b0, W1, b1, ...]; bn = [gamma0, beta0, ...]; stats = [running_mean0, running_var0, ...] (updated in place
+    in training mode, exactly as nn.BatchNorm1d does: momentum 0.1, unbiased variance)."""
+    n_layers = len(lin) // 2
+    for l in range(n_layers):
+        x = F.linear(x, lin[2 * l], lin[2 * l + 1])
+        if l < n_layers - 1:
+            x = F.elu(F.batch_norm(x, stats[2 * l], stats[2 * l + 1], bn[2 * l], bn[2 * l + 1], training, momentum, eps))
+    return x
+
+
+class CrossQRef:
+    """AgentCrossQ.update_net inner iteration (pql/algo/crossQ.py:120-166), no_tgt_actor=True: joint BatchNorm-critic
+    forward over [obs; next_obs], target from the detached next half, twin MSE; DPG actor step through the critic in
+    training mode; no target networks."""
+
+    def __init__(self, obs_dim, act_dim, hp: HyperRef, capacity, actor, q_lin, q_bn):
+        """q_lin[n] / q_bn[n]: Linear and BatchNorm parameter lists of net n."""
+        self.hp = hp
+        self.actor = [p.clone().requires_grad_(True) for p in actor]
+        self.q_lin = [[p.clone().requires_grad_(True) for p in net] for net in q_lin]
+        self.q_bn = [[p.clone().requires_grad_(True) for p in net] for net in q_bn]
+        self.q_stats = []
+        for net in q_bn:
+            st = []
+            for g in net[0::2]:
+                st += [torch.zeros_like(g), torch.ones_like(g)]
+            self.q_stats.append(st)
+        self.aopt = AdamWRef(self.actor, lr=hp.actor_lr)
+        self.cparams = [*self.q_lin[0], *self.q_bn[0], *self.q_lin[1], *self.q_bn[1]]
+        self.copt = AdamWRef(self.cparams, lr=hp.critic_lr)
+        self.ring = RingRef(capacity, obs_dim, act_dim)
+        self.norm = None
+
+    def q12(self, obs, act, lin=None, bn=None):
+        x = torch.cat((obs, act), dim=1)
+        lin, bn = lin or self.q_lin, bn or self.q_bn
+        return tuple(bn_mlp_forward_ref(lin[n], bn[n], self.q_stats[n], x, training=True) for n in range(2))
+
+    def update_once(self, idx, draw):
+        hp = self.hp
+        obs, act, rew, nobs, done = self.ring.gather(idx)
+        if hp.obs_norm:
+            obs = normalize_ref(obs, self.norm, clamp=False); nobs = normalize_ref(nobs, self.norm, clamp=False)
+        with torch.no_grad():
+            na = target_noise_ref(actor_forward_ref(self.actor, nobs), draw, hp.tgt_pol_std, hp.tgt_pol_noise_bound)
+        a1, a2 = self.q12(torch.cat((obs, nobs), dim=0), torch.cat((act, na), dim=0))
+        B = obs.shape[0]
+        tgt = rew + (1 - done) * (hp.gamma ** hp.nstep) * torch.min(a1[B:].detach(), a2[B:].detach())
+        closs = F.mse_loss(a1[:B], tgt) + F.mse_loss(a2[:B], tgt)
+        self.copt.apply(list(torch.autograd.grad(closs, self.cparams)), hp.max_grad_norm)
+        flin = [[p.detach() for p in net] for net in self.q_lin]; fbn = [[p.detach() for p in net] for net in self.q_bn]
+        q1, q2 = self.q12(obs, actor_forward_ref(self.actor, obs), flin, fbn)
+        aloss = -torch.min(q1, q2).mean()
+        self.aopt.apply(list(torch.autograd.grad(aloss, self.actor)), hp.max_grad_norm)
+        return float(closs.detach()), float(aloss.detach())

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Single-process off-policy baseline loop (DDPG, SAC: `algo=ddpg_algo` / `algo=sac_algo`) -- same shape as the reference's scripts/train_baselines.py:39-72:
+"""Single-process off-policy baseline loop (DDPG, SAC, CrossQ: `algo=ddpg_algo` / `sac_algo` / `crossq_algo`) -- same shape as the reference's scripts/train_baselines.py:39-72:
 warm-up rollout -> replay, then per iteration: rollout, insert, `agent.update_net(memory)`.
     python scripts/train_baselines.py algo=ddpg_algo task.name=Toy num_envs=64 algo.batch_size=256 algo.memory_size=100000 max_step=20000
 """

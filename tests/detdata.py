@@ -67,6 +67,19 @@ def doubleq_state(obs_dim, act_dim, out_dim, seed, hidden=(512, 256, 128)):
     return s
 
 
+def bn_critic_state(O, A, seed, hidden=(512, 256, 128)):
+    """Reference-keyed state of DoubleQBatchNorm: Linear weights as in doubleq_state (keys 0,3,6,9), non-trivial gamma / beta."""
+    st = {}
+    for n, pre in enumerate(("net_q1.net.", "net_q2.net.")):
+        lin = mlp_state(O + A, 1, seed + n, hidden, prefix="")
+        for l in range(len(hidden) + 1):
+            st[f"{pre}{3 * l}.weight"] = lin[f"{2 * l}.weight"]; st[f"{pre}{3 * l}.bias"] = lin[f"{2 * l}.bias"]
+            if l < len(hidden):
+                st[f"{pre}{3 * l + 1}.weight"] = uniform((hidden[l],), 9000 + 10 * (seed + n) + l, 0.5, 1.5)
+                st[f"{pre}{3 * l + 1}.bias"] = uniform((hidden[l],), 9500 + 10 * (seed + n) + l, -0.2, 0.2)
+    return st
+
+
 def probe_indices(n, k=256, seed=7):
     """Deterministic sample positions used to summarise a large tensor in a fixture."""
     if n <= k:

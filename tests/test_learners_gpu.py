@@ -434,3 +434,123 @@ def test_train_baselines_entry_point_sac(dev):
                              "device=cuda:0", "sim_device=cuda:0", "max_step=4000", "algo.update_times=4"]))
     assert out["global_steps"] > 4000 and np.isfinite(out["train/critic_loss"]) and np.isfinite(out["train/actor_loss"])
     assert 0 < out["train/alpha"] < 1.0   # entropy above target at the start: the temperature decreases from 1
+
+
+# --------------------------------------------------------------------------- CrossQ
+def _crossq_cfg(extra=()):
+    from pql_amd.utils.cfg import load_cfg
+    return load_cfg(["algo=crossq_algo", "task.name=Toy", "num_envs=64", "algo.batch_size=64", "algo.memory_size=400",
+                     "device=cuda:0", "sim_device=cuda:0", *extra])
+
+
+def _check_bn_critic(critic, g, prefix, skip_pre_norm_bias=True):
+    for key, view in critic.named_views():
+        layer = int(key.split(".")[2])
+        if skip_pre_norm_bias and key.endswith(".bias") and layer % 3 == 0 and layer < 9:
+            continue   # zero-gradient parameter moved by Adam on rounding noise: see tests/test_oracle_golden.py::test_crossq_trace
+        np.testing.assert_allclose(dd.summarize(view.cpu().numpy()), g[f"{prefix}{key}"], rtol=5e-5, atol=1e-5, err_msg=prefix + key)
+
+
+def test_batchnorm_critic_forward_golden(golden, dev):
+    """DoubleQBatchNorm (one-layer GEMM calls + pqlk_batch_moments + pqlk_bn_elu_forward) vs the reference module: training
+    mode on a 128-row batch, the running statistics it leaves, then eval mode."""
+    from pql_amd.models.batchnorm import DoubleQBatchNorm
+    g = golden("crossq"); O, A, B = 8, 2, 64
+    q = DoubleQBatchNorm((O,), A).to(dev)
+    q.load_state_dict(_sd(dd.bn_critic_state(O, A, 41)), strict=False)
+    xk, ak = T(dd.uniform((2 * B, O), 71, -2, 2)).to(dev), T(dd.uniform((2 * B, A), 72, -1, 1)).to(dev)
+    q.train()
+    q1, q2 = q.get_q1_q2(xk, ak)
+    np.testing.assert_allclose(q1.cpu().numpy(), g["cq_kat_train_q1"], atol=5e-6); np.testing.assert_allclose(q2.cpu().numpy(), g["cq_kat_train_q2"], atol=5e-6)
+    sd = q.state_dict()
+    np.testing.assert_allclose(sd["net_q1.net.1.running_mean"].cpu().numpy(), g["cq_kat_running_mean_l0"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sd["net_q1.net.1.running_var"].cpu().numpy(), g["cq_kat_running_var_l0"], rtol=1e-5)
+    assert int(sd["net_q2.net.7.num_batches_tracked"]) == 1
+    q.eval()
+    q1, q2 = q.get_q1_q2(xk, ak)
+    np.testing.assert_allclose(q1.cpu().numpy(), g["cq_kat_eval_q1"], atol=5e-6); np.testing.assert_allclose(q2.cpu().numpy(), g["cq_kat_eval_q2"], atol=5e-6)
+    assert int(q.state_dict()["net_q2.net.7.num_batches_tracked"]) == 1            # eval does not touch the statistics
+    np.testing.assert_allclose(q.get_q_min(xk, ak).cpu().numpy(), np.minimum(g["cq_kat_eval_q1"], g["cq_kat_eval_q2"]), atol=5e-6)
+
+
+def test_crossq_golden_trace(golden, dev):
+    """AgentCrossQ.update_once (HIP) vs three iterations of the reference's AgentCrossQ.update_critic / update_actor: losses,
+    actor, Linear weights, BatchNorm gamma / beta and running statistics."""
+    from pql_amd.algo.crossq import AgentCrossQ
+    from pql_amd.envs.synthetic import create_task_env
+    from pql_amd.replay.simple_replay import ReplayBuffer
+    g = golden("crossq"); O, A = 8, 2
+    cfg = _crossq_cfg()
+    agent = AgentCrossQ(create_task_env(cfg), cfg)
+    agent.actor.load_state_dict(_sd(dd.mlp_state(O, A, 11)))
+    agent.critic.load_state_dict(_sd(dd.bn_critic_state(O, A, 41)), strict=False)
+    agent.obs_rms.mean, agent.obs_rms.var = T(g["cq_norm_mean"]).to(dev), T(g["cq_norm_var"]).to(dev)
+    memory = ReplayBuffer(400, (O,), A, device=dev)
+    memory.add_to_buffer(tuple(t.to(dev) for t in _fill(O, A, 300, 810)))
+    for s in range(3):
+        agent.update_once(memory, indices=T(g["cq_idx"][s]), noise=T(g["cq_noise"][s]))
+        np.testing.assert_allclose(agent.closs[s % 5].item(), g["cq_closs"][s], rtol=2e-5)
+        np.testing.assert_allclose(agent.aloss[s % 5].item(), g["cq_aloss"][s], rtol=2e-5)
+        _check_module(agent.actor, g, f"cq_s{s}_a_")
+        _check_bn_critic(agent.critic, g, f"cq_s{s}_c_")
+        sd = agent.critic.state_dict()
+        for k in sd:
+            if k.endswith("running_var"):
+                np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"cq_s{s}_r_{k}"], rtol=2e-5, atol=2e-6, err_msg=k)
+            if k.endswith("running_mean"):   # contains the incomparable pre-norm bias (see the oracle test)
+                np.testing.assert_allclose(sd[k].cpu().numpy(), g[f"cq_s{s}_r_{k}"], rtol=2e-5, atol=5e-4, err_msg=k)
+    np.testing.assert_allclose(agent.actor.layout.weight(agent.actor.arena.data, 0, 3).cpu().numpy(), g["cq_final_actor_last_w"],
+                               rtol=5e-5, atol=5e-7)
+    np.testing.assert_allclose(agent.critic.weight(0, 3).cpu().numpy(), g["cq_final_q1_last_w"], rtol=5e-5, atol=1e-5)
+    np.testing.assert_allclose(agent.critic.bn_param(0, 0, "gamma").cpu().numpy(), g["cq_final_q1_bn0_gamma"], rtol=5e-5, atol=1e-5)
+
+
+def test_crossq_update_vs_oracle_allegro_shape(dev):
+    """AllegroHand shapes, batch 2048 (joint critic batch 4096), default hidden sizes: two iterations vs the oracle's CrossQRef."""
+    from oracle import pql_ref_cpu as ref
+    from pql_amd.algo.crossq import AgentCrossQ
+    from pql_amd.envs.synthetic import create_task_env
+    from pql_amd.replay.simple_replay import ReplayBuffer
+    O, A, B, rows = 88, 16, 2048, 5000
+    cfg = _crossq_cfg(["task.name=AllegroHand", f"algo.batch_size={B}", "algo.memory_size=8000"])
+    agent = AgentCrossQ(create_task_env(cfg), cfg)
+    ast, cst = dd.mlp_state(O, A, 11), dd.bn_critic_state(O, A, 41)
+    agent.actor.load_state_dict(_sd(ast)); agent.critic.load_state_dict(_sd(cst), strict=False)
+    mean, var = T(dd.uniform((O,), 801, -0.5, 0.5)), T(dd.uniform((O,), 802, 0.5, 2.0))
+    agent.obs_rms.mean, agent.obs_rms.var = mean.to(dev), var.to(dev)
+    data = _fill(O, A, rows, 77)
+    memory = ReplayBuffer(8000, (O,), A, device=dev)
+    memory.add_to_buffer(tuple(t.to(dev) for t in data))
+    lin, bn = [], []
+    for pre in ("net_q1.net.", "net_q2.net."):
+        lin.append([T(cst[f"{pre}{3 * l}.{k}"]) for l in range(4) for k in ("weight", "bias")])
+        bn.append([T(cst[f"{pre}{3 * l + 1}.{k}"]) for l in range(3) for k in ("weight", "bias")])
+    orc = ref.CrossQRef(O, A, ref.HyperRef(batch_size=B), 8000, ref.params_from_state(ast), lin, bn)
+    orc.ring.insert(*data); orc.norm = (mean, var, 1e-4)
+    for s in range(2):
+        idx, draw = T(dd.integers((B,), 40 + s, rows)), T(dd.uniform((B, A), 50 + s, -2, 2))
+        cl, al_ = orc.update_once(idx, draw)
+        agent.update_once(memory, indices=idx, noise=draw)
+        np.testing.assert_allclose(agent.closs[s % 5].item(), cl, rtol=5e-5)
+        np.testing.assert_allclose(agent.aloss[s % 5].item(), al_, rtol=5e-5, atol=1e-6)
+    for n in range(2):
+        for l in range(4):
+            np.testing.assert_allclose(agent.critic.weight(n, l).cpu().numpy(), orc.q_lin[n][2 * l].detach().numpy(), rtol=1e-5, atol=1e-5)
+            if l < 3:
+                np.testing.assert_allclose(agent.critic.bn_param(n, l, "gamma").cpu().numpy(), orc.q_bn[n][2 * l].detach().numpy(), rtol=1e-5, atol=1e-5)
+                np.testing.assert_allclose(agent.critic.bn_param(n, l, "beta").cpu().numpy(), orc.q_bn[n][2 * l + 1].detach().numpy(), rtol=1e-5, atol=1e-5)
+                np.testing.assert_allclose(agent.critic.running(n, l, "var").cpu().numpy(), orc.q_stats[n][2 * l + 1].numpy(), rtol=2e-5, atol=2e-6)
+    for l in range(agent.actor.layout.n_layers):
+        np.testing.assert_allclose(agent.actor.layout.weight(agent.actor.arena.data, 0, l).cpu().numpy(),
+                                   orc.actor[2 * l].detach().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_train_baselines_entry_point_crossq(dev):
+    import importlib.util, os
+    from pql_amd.utils.cfg import load_cfg
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("train_baselines", os.path.join(root, "scripts", "train_baselines.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    out = mod.main(load_cfg(["algo=crossq_algo", "task.name=Toy", "num_envs=64", "algo.batch_size=256", "algo.memory_size=100000",
+                             "device=cuda:0", "sim_device=cuda:0", "max_step=4000", "algo.update_times=4"]))
+    assert out["global_steps"] > 4000 and np.isfinite(out["train/critic_loss"]) and np.isfinite(out["train/actor_loss"])

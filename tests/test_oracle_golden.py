@@ -299,3 +299,60 @@ def test_sac_trace(golden):
         _check_params(zip(cn, [*s.t1, *s.t2]), g, f"sac_s{i}_t_")
     np.testing.assert_allclose(s.actor[-2].detach().numpy(), g["sac_final_actor_last_w"], rtol=5e-5, atol=5e-7)
     np.testing.assert_allclose(s.q1[-2].detach().numpy(), g["sac_final_q1_last_w"], rtol=5e-5, atol=5e-7)
+
+
+# --------------------------------------------------------------------------- CrossQ
+def _bn_lists(state, hidden=(512, 256, 128)):
+    lin, bn = [], []
+    for pre in ("net_q1.net.", "net_q2.net."):
+        lin.append([T(state[f"{pre}{3 * l}.{k}"]) for l in range(len(hidden) + 1) for k in ("weight", "bias")])
+        bn.append([T(state[f"{pre}{3 * l + 1}.{k}"]) for l in range(len(hidden)) for k in ("weight", "bias")])
+    return lin, bn
+
+
+def test_crossq_trace(golden):
+    """CrossQRef vs the reference's DoubleQBatchNorm (train- and eval-mode forward incl. running statistics) and three
+    iterations of AgentCrossQ.update_critic / update_actor."""
+    g = golden("crossq"); O, A, B = 8, 2, 64
+    lin, bn = _bn_lists(dd.bn_critic_state(O, A, 41))
+    s = ref.CrossQRef(O, A, ref.HyperRef(batch_size=B), 400, ref.params_from_state(dd.mlp_state(O, A, 11)), lin, bn)
+    # known-answer forward on a probe copy of the statistics
+    xk, ak = T(dd.uniform((2 * B, O), 71, -2, 2)), T(dd.uniform((2 * B, A), 72, -1, 1))
+    saved = [[t.clone() for t in st] for st in s.q_stats]
+    with torch.no_grad():
+        q1, q2 = s.q12(xk, ak)
+        np.testing.assert_allclose(q1.numpy(), g["cq_kat_train_q1"], atol=2e-6); np.testing.assert_allclose(q2.numpy(), g["cq_kat_train_q2"], atol=2e-6)
+        np.testing.assert_allclose(s.q_stats[0][0].numpy(), g["cq_kat_running_mean_l0"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(s.q_stats[0][1].numpy(), g["cq_kat_running_var_l0"], rtol=1e-6)
+        x = torch.cat((xk, ak), dim=1)
+        e1 = ref.bn_mlp_forward_ref(s.q_lin[0], s.q_bn[0], s.q_stats[0], x, training=False)
+        e2 = ref.bn_mlp_forward_ref(s.q_lin[1], s.q_bn[1], s.q_stats[1], x, training=False)
+        np.testing.assert_allclose(e1.numpy(), g["cq_kat_eval_q1"], atol=2e-6); np.testing.assert_allclose(e2.numpy(), g["cq_kat_eval_q2"], atol=2e-6)
+    s.q_stats = saved
+    s.ring.insert(*_fill(O, A, 300, 810))
+    s.norm = (T(g["cq_norm_mean"]), T(g["cq_norm_var"]), 1e-4)
+    for i in range(3):
+        cl, al = s.update_once(T(g["cq_idx"][i]), T(g["cq_noise"][i]))
+        np.testing.assert_allclose(cl, g["cq_closs"][i], rtol=2e-5)
+        np.testing.assert_allclose(al, g["cq_aloss"][i], rtol=2e-5)
+        _check_params(zip(_named(["net."], [s.actor]), s.actor), g, f"cq_s{i}_a_")
+        for n, pre in enumerate(("net_q1.net.", "net_q2.net.")):
+            for l in range(4):
+                for j, k in enumerate(("weight", "bias")):
+                    # the bias of a Linear that feeds a BatchNorm has an analytically ZERO gradient (the norm removes any
+                    # per-column shift): what reaches AdamW is rounding noise, which m / sqrt(v) turns into +-lr steps of
+                    # arbitrary sign -- not comparable between any two implementations, and without effect on the outputs
+                    if k == "bias" and l < 3:
+                        continue
+                    np.testing.assert_allclose(dd.summarize(s.q_lin[n][2 * l + j].detach().numpy()), g[f"cq_s{i}_c_{pre}{3 * l}.{k}"],
+                                               rtol=5e-5, atol=1e-5, err_msg=f"{pre}{3 * l}.{k}")
+                    if l < 3:
+                        np.testing.assert_allclose(dd.summarize(s.q_bn[n][2 * l + j].detach().numpy()), g[f"cq_s{i}_c_{pre}{3 * l + 1}.{k}"],
+                                                   rtol=5e-5, atol=1e-5)   # 2 % of one lr step (DESIGN section 2: Adam on ~0 gradients)
+                if l < 3:
+                    # running_mean contains the (incomparable, see above) pre-norm bias: <= momentum * sum of its +-lr steps
+                    np.testing.assert_allclose(s.q_stats[n][2 * l].numpy(), g[f"cq_s{i}_r_{pre}{3 * l + 1}.running_mean"], rtol=2e-5, atol=5e-4)
+                    np.testing.assert_allclose(s.q_stats[n][2 * l + 1].numpy(), g[f"cq_s{i}_r_{pre}{3 * l + 1}.running_var"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(s.actor[-2].detach().numpy(), g["cq_final_actor_last_w"], rtol=5e-5, atol=5e-7)
+    np.testing.assert_allclose(s.q_lin[0][-2].detach().numpy(), g["cq_final_q1_last_w"], rtol=5e-5, atol=1e-5)
+    np.testing.assert_allclose(s.q_bn[0][0].detach().numpy(), g["cq_final_q1_bn0_gamma"], rtol=5e-5, atol=1e-5)

@@ -82,6 +82,8 @@ def _import_reference():
     from pql.algo.pql_p_learner import PQLPLearner
     from pql.models.mlp import TanhDiagGaussianMLPPolicy
     from pql.algo.sac import AgentSAC
+    from pql.models.mlp import DoubleQBatchNorm
+    from pql.algo.crossQ import AgentCrossQ
     return NS(**locals())
 
 
@@ -505,13 +507,66 @@ def gen_sac(R, out, steps=3):
     out["sac_norm_mean"] = norm[0]; out["sac_norm_var"] = norm[1]
 
 
+# --------------------------------------------------------------------------- CrossQ
+def gen_crossq(R, out, steps=3):
+    O, A, B = 8, 2, 64
+    norm = (dd.uniform((O,), 801, -0.5, 0.5), dd.uniform((O,), 802, 0.5, 2.0))
+    cfg = NS(info_track_keys=None, device="cpu",
+             algo=NS(batch_size=B, obs_norm=True, gamma=0.99, nstep=3, tau=0.05, max_grad_norm=0.5, no_tgt_actor=True, update_times=1,
+                     noise=NS(tgt_pol_std=0.8, tgt_pol_noise_bound=0.2)))
+    s = R.AgentCrossQ.__new__(R.AgentCrossQ)
+    s.cfg, s.obs_dim, s.action_dim, s.device = cfg, (O,), A, torch.device("cpu")
+    s.actor = R.TanhMLPPolicy((O,), A); load_state(s.actor, dd.mlp_state(O, A, 11))
+    s.actor_target = s.actor
+    s.critic = R.DoubleQBatchNorm((O,), A)
+    s.critic.load_state_dict({k: T(v) for k, v in dd.bn_critic_state(O, A, 41).items()}, strict=False)
+    s.actor_optimizer = torch.optim.AdamW(s.actor.parameters(), 5e-4)
+    s.critic_optimizer = torch.optim.AdamW(s.critic.parameters(), 5e-4)
+    s.obs_rms = R.RunningMeanStd(shape=(O,), device="cpu"); s.obs_rms.mean, s.obs_rms.var = T(norm[0]), T(norm[1])
+    data = [T(d) for d in _fill_data(O, A, 300, 810)]
+    # forward known-answer vector (training mode on a 2B batch, then eval mode with the moved running statistics)
+    xk, ak = T(dd.uniform((2 * B, O), 71, -2, 2)), T(dd.uniform((2 * B, A), 72, -1, 1))
+    probe = deepcopy(s.critic)
+    with torch.no_grad():
+        q1, q2 = probe.get_q1_q2(xk, ak)
+        out["cq_kat_train_q1"], out["cq_kat_train_q2"] = q1.numpy(), q2.numpy()
+        probe.eval()
+        q1, q2 = probe.get_q1_q2(xk, ak)
+        out["cq_kat_eval_q1"], out["cq_kat_eval_q2"] = q1.numpy(), q2.numpy()
+    out["cq_kat_running_mean_l0"] = probe.state_dict()["net_q1.net.1.running_mean"].numpy().copy()
+    out["cq_kat_running_var_l0"] = probe.state_dict()["net_q1.net.1.running_var"].numpy().copy()
+    closs, aloss, idxs = [], [], []
+    with _Capture(8700) as cap:     # torch.normal of add_normal_noise
+        for st in range(steps):
+            idx = T(dd.integers((B,), 8800 + st, 300)); idxs.append(idx.numpy())
+            obs, act, rew, nobs, done = (d[idx] for d in data)
+            obs, nobs = s.obs_rms.normalize(obs), s.obs_rms.normalize(nobs)
+            cl, _ = s.update_critic(obs, act, rew, nobs, done)
+            al, _ = s.update_actor(obs)
+            closs.append(cl); aloss.append(al)
+            for k, p in s.actor.named_parameters():
+                out[f"cq_s{st}_a_{k}"] = dd.summarize(p.detach().numpy())
+            for k, p in s.critic.named_parameters():
+                out[f"cq_s{st}_c_{k}"] = dd.summarize(p.detach().numpy())
+            sd = s.critic.state_dict()
+            for k in sd:
+                if "running" in k:
+                    out[f"cq_s{st}_r_{k}"] = sd[k].numpy().copy()
+    out["cq_closs"] = np.array(closs, np.float64); out["cq_aloss"] = np.array(aloss, np.float64)
+    out["cq_idx"] = np.stack(idxs); out["cq_noise"] = np.stack(cap.noise)
+    out["cq_final_actor_last_w"] = s.actor.state_dict()["net.6.weight"].numpy().copy()
+    out["cq_final_q1_last_w"] = s.critic.state_dict()["net_q1.net.9.weight"].numpy().copy()
+    out["cq_final_q1_bn0_gamma"] = s.critic.state_dict()["net_q1.net.1.weight"].numpy().copy()
+    out["cq_norm_mean"] = norm[0]; out["cq_norm_var"] = norm[1]
+
+
 def main():
     torch.set_num_threads(1)
     torch.manual_seed(0)
     R = _import_reference()
     os.makedirs(OUT, exist_ok=True)
     for name, fn in (("replay", gen_ring), ("nstep", gen_nstep), ("models", gen_models), ("math", gen_math),
-                     ("learners", gen_learners), ("sac", gen_sac)):
+                     ("learners", gen_learners), ("sac", gen_sac), ("crossq", gen_crossq)):
         out = {}
         with torch.no_grad() if name in ("replay", "nstep") else contextlib.nullcontext():
             fn(R, out)
