@@ -13,7 +13,7 @@ import csv
 import json
 import sys
 
-MFMA = ("k_gemm", "k_mlp_fwd_fused")
+MFMA = ("k_gemm", "k_mlp_fwd_fused", "k_fwd_narrow", "k_dx_slice")
 GATHER = ("k_replay_gather_fast", "k_replay_gather_fused")
 
 
