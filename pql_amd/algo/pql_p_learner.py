@@ -12,7 +12,6 @@ learn()  (reference :47-64)  ->  one launch sequence
 from __future__ import annotations
 
 import contextlib
-import os
 import ctypes as C
 import time
 from copy import deepcopy

@@ -15,7 +15,6 @@ is captured once into a hipGraph (through torch.cuda.CUDAGraph) and replayed.
 from __future__ import annotations
 
 import contextlib
-import os
 import ctypes as C
 import time
 from copy import deepcopy

@@ -1,7 +1,6 @@
 """`soft_update` and `RunningMeanStd` with the reference's names (pql/utils/torch_util.py:9-12, :68-114)."""
 from __future__ import annotations
 
-import ctypes as C
 
 import torch
 
