@@ -231,3 +231,45 @@ def test_evaluator_module_spec_round_trip_is_plain_data():
         clone = type(mod)(**spec["kwargs"])
         clone.load_state_dict(spec["state"])
         assert torch.equal(clone.arena.data, mod.arena.data)
+
+
+def test_c_abi_reports_argument_errors_as_codes():
+    """Error behaviour of the boundary (include/pqlk.h): bad arguments come back as positive PQLK_E_* codes before anything
+    is launched -- no exception across the ABI, no abort, no launch (so this runs without a GPU).  0x1000 stands in for a
+    device pointer: argument validation never dereferences it."""
+    import ctypes as C
+    from pql_amd import _lib as L
+    E_NULL, E_SHAPE, E_ALIGN, E_UNSUPPORTED = 1, 2, 4, 5
+    P = C.c_void_p(0x1000)
+    d = L.mlp_desc([8, 64, 1], 2)
+    lib = L.lib
+    # MLP forward / backward
+    assert lib.pqlk_mlp_forward(None, P, None, 1, P, 32, 4, L.ACT_NONE, None, 0.0, 0.0, P, None, 0, None) == E_NULL
+    assert lib.pqlk_mlp_forward(C.byref(d), None, None, 1, P, 32, 4, L.ACT_NONE, None, 0.0, 0.0, P, None, 0, None) == E_NULL
+    assert lib.pqlk_mlp_forward(C.byref(d), P, None, 1, P, 32, 0, L.ACT_NONE, None, 0.0, 0.0, P, None, 0, None) == E_SHAPE
+    assert lib.pqlk_mlp_forward(C.byref(d), P, None, 1, P, 20, 4, L.ACT_NONE, None, 0.0, 0.0, P, None, 0, None) == E_ALIGN      # ldx % 32
+    assert lib.pqlk_mlp_forward(C.byref(d), C.c_void_p(0x1004), None, 1, P, 32, 4, L.ACT_NONE, None, 0.0, 0.0, P, None, 0, None) == E_ALIGN
+    assert lib.pqlk_mlp_forward(C.byref(d), P, None, 1, P, 32, 4, 99, None, 0.0, 0.0, P, None, 0, None) == E_UNSUPPORTED        # activation id
+    assert lib.pqlk_mlp_forward(C.byref(d), P, None, 1, P, 32, 4, L.ACT_TANH_NOISE, None, 0.5, 0.2, P, None, 0, None) == E_NULL  # noise needs a draw
+    d3 = L.mlp_desc([8, 64, 1], 3)
+    assert lib.pqlk_mlp_forward(C.byref(d3), P, None, 1, P, 32, 4, L.ACT_NONE, None, 0.0, 0.0, P, None, 0, None) == E_UNSUPPORTED  # n_nets > 2
+    assert lib.pqlk_mlp_backward(C.byref(d), P, P, 32, 4, P, None, P, 1, None, 0, 0, 0, None, 0, P, 1 << 20, None) == E_NULL      # dy
+    # replay / n-step
+    ring = L.PqlReplayDesc(0x1000, 100, 8, 2, int(lib.pqlk_replay_rec_ld(8, 2)), 0)
+    assert lib.pqlk_replay_gather(C.byref(ring), None, 4, P, P, P, P, P, None) == E_NULL
+    assert lib.pqlk_replay_gather(None, P, 4, P, P, P, P, P, None) == E_NULL
+    assert lib.pqlk_replay_insert(C.byref(ring), 98, 4, P, 8, P, 2, P, 1, P, 8, P, 1, None) != 0      # rows 98..101 of a 100-row ring
+    # losses / optimiser
+    assert lib.pqlk_td_mse_loss(P, P, 32, P, P, 0.97, 0, P, P, None, 1, P, None) == E_SHAPE
+    assert lib.pqlk_clip_adamw_polyak(P, P, P, P, None, 0, 1.0, 0.5, 5e-4, 0.9, 0.999, 1e-8, 1e-2, 0.05, P, None, P, None) == E_SHAPE
+    assert lib.pqlk_clip_adamw_polyak(P, None, P, P, None, 64, 1.0, 0.5, 5e-4, 0.9, 0.999, 1e-8, 1e-2, 0.05, P, None, P, None) == E_NULL
+    # SAC head, BatchNorm block, synthetic env
+    assert lib.pqlk_sg_head_forward(P, 32, P, 4, 65, P, 65, P, None) == E_SHAPE          # more than 64 actions
+    assert lib.pqlk_sg_head_forward(P, 8, P, 4, 8, P, 8, P, None) == E_SHAPE             # ld_y < 2 A
+    assert lib.pqlk_sg_head_backward(P, 32, None, P, 8, P, 8, None, 1.0, 4, 8, P, None) == E_NULL
+    assert lib.pqlk_bn_elu_forward(P, 64, 1, 64, P, P, P, P, 1e-5, 1, 0.1, P, P, P, None) == E_SHAPE   # one row has no variance
+    assert lib.pqlk_bn_elu_forward(P, 64, 8, 64, None, None, P, P, 1e-5, 1, 0.1, P, P, P, None) == E_NULL
+    assert lib.pqlk_bn_elu_backward(P, P, P, 32, 8, 64, P, P, P, 1e-5, P, None, None, P, None) == E_SHAPE  # ld < cols
+    assert lib.pqlk_synth_env_step(0, 8, 2, 1, 0, 1, 0.01, P, P, P, P, None) == E_SHAPE
+    for code in (E_NULL, E_SHAPE, 3, E_ALIGN, E_UNSUPPORTED, 6):
+        assert len(lib.pqlk_strerror(code)) > 2
