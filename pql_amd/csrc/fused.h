@@ -38,6 +38,12 @@ struct FusedP {
   int dims[PQLK_MAX_LAYERS + 1];  // in (logical), h1, h2, ...
   long long net_stride, packed_net_stride;
   long long b_off[PQLK_MAX_LAYERS], p_off[PQLK_MAX_LAYERS], a_off[PQLK_MAX_LAYERS];
+  // optional fused output layer (<= 32 outputs): weights read row-major from the arena, no packed copy
+  int head_n, head_epi, head_ld, ld_out2;      // head_n = 0: the caller launches the last layer itself
+  long long head_w_off, head_b_off, head_a_off;
+  const float* draw;                           // (B, head_n) standard-normal draw for HEAD_TANH_NOISE
+  float* out2;                                 // optional second destination of the output (net 0), row stride ld_out2
+  float noise_std, noise_clip;
 #if defined(PQLK_FP_CLK)   // tuning probe only (tools/probes/fused_probe.hip): shader-clock stamps of one wave
   long long* clk;
 #endif
@@ -202,6 +208,70 @@ __device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, in
   FP_TICK(4);
 }
 
+// Output layer fused behind the hidden stack: Linear(K_h -> N <= 32) + {none, tanh, tanh + clipped target-policy noise}
+// (+ second store), reference mlp.py:15-24,179 and pql_v_learner.py:62-71.  The 32 R x N outputs of a block are a
+// sliver of MFMA work (K_h / 8 x 4 x R instructions), so the reduction range is SPLIT over the 8 waves, the partial tiles
+// go through LDS (over the activation buffer, once every wave has read it) and are summed in wave order by all threads
+// together with bias and activation.  That replaces a separate launch per forward (k_fwd_narrow / k_skinny_fwd: 6-10 us
+// each); the summation order differs from theirs by reassociation only.
+enum { HEAD_NONE = PQLK_ACT_NONE, HEAD_TANH = PQLK_ACT_TANH, HEAD_TANH_NOISE = PQLK_ACT_TANH_NOISE };
+
+template <int R>
+__device__ __forceinline__ void fused_head(const FusedP& p, int net, int row0, int buf_ld4, int wave, int lane) {
+  constexpr int NW = FUSED_NW;
+  const int r = lane & 31, h = lane >> 5;
+  const int Kh = p.dims[p.n_hidden], K8 = Kh >> 3, N = p.head_n;
+  const float* W = p.params + (long long)net * p.net_stride + p.head_w_off;     // (N, Kh) row-major: Kh % 32 == 0 -> ld = Kh
+  const float4* wp = reinterpret_cast<const float4*>(W + (long long)min(r, N - 1) * Kh) + h;   // rows past N: clamped, never stored
+  const float4* lds4 = reinterpret_cast<const float4*>(fsm);
+  const int per = (K8 + NW - 1) / NW, k0 = wave * per, k1 = min(K8, k0 + per);
+  f32x16f acc[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+  for (int k8 = k0; k8 < k1; ++k8) {
+    const float4 w4 = wp[2 * k8];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const float4 a4 = lds4[(32 * i + r) * buf_ld4 + 2 * k8 + h];
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.x, a4.x, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.y, a4.y, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.z, a4.z, acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, a4.w, acc[i], 0, 0, 0);
+    }
+  }
+  __syncthreads();   // every wave is done reading the activations
+#pragma unroll
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) fsm[((wave * R + i) * 16 + e) * 64 + lane] = acc[i][e];
+  __syncthreads();
+  const float* bias = p.params + (long long)net * p.net_stride + p.head_b_off;
+  float* out = p.acts + p.head_a_off + (long long)net * p.B * p.head_ld;
+  for (int o = wave * 64 + lane; o < 32 * R * p.head_ld; o += 64 * NW) {
+    const int row = o / p.head_ld, c = o - row * p.head_ld;
+    if (row0 + row >= p.B) continue;
+    float x = 0.f;   // pad column
+    if (c < N) {
+      const int i = row >> 5, ln = (row & 31) + 32 * ((c >> 2) & 1), e = 4 * (c >> 3) + (c & 3);   // accumulator slot of (row, c)
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s += fsm[((w * R + i) * 16 + e) * 64 + ln];
+      x = s + bias[c];
+      if (p.head_epi == HEAD_TANH) x = tanhf(x);
+      else if (p.head_epi == HEAD_TANH_NOISE) {
+        x = tanhf(x);
+        float nz = p.noise_std * p.draw[(long long)(row0 + row) * N + c];
+        nz = fminf(fmaxf(nz, -p.noise_clip), p.noise_clip);
+        x = fminf(fmaxf(x + nz, -1.f), 1.f);
+      }
+      if (p.out2 && net == 0) p.out2[(long long)(row0 + row) * p.ld_out2 + c] = x;
+    }
+    out[(long long)(row0 + row) * p.head_ld + c] = x;
+  }
+}
+
 // R row tiles of 32 per block; TM = widest per-wave tile count any layer needs (2: widths <= 512, 4: <= 1024)
 template <int R, int TM>
 __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
@@ -287,6 +357,7 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
       fused_layer<R, 1, TM, D>(bq, buf_ld4, K8, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n, ntiles_n,
                                tpw_n, gprev, nprev4 FP_CLKARG);
   }
+  if (p.head_n > 0) fused_head<R>(p, net, row0, buf_ld4, wave, lane);   // the LDS buffer holds the last hidden layer's output
 }
 
 // arena -> fragment-ordered copy of the hidden layers' weights (one thread per element; 1-3 M elements)

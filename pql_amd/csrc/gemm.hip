@@ -505,7 +505,9 @@ extern "C" int64_t pqlk_mlp_bwd_ws_floats(const PqlMlpDesc* d, int64_t b, int32_
 // fusable: at least one hidden layer, hidden widths multiples of 32 and <= 1024 (4 output tiles per wave), and one
 // 32-row activation tile + the bias table within the 160 KB of LDS
 static size_t fused_lds_bytes(const PqlMlpDesc* d, int buf_ld, int R) {
-  return ((size_t)32 * R * buf_ld + (size_t)(d->n_layers - 1) * (buf_ld - 4)) * sizeof(float);
+  const size_t acts = ((size_t)32 * R * buf_ld + (size_t)(d->n_layers - 1) * (buf_ld - 4)) * sizeof(float);
+  const size_t head = (size_t)8 * R * 16 * 64 * sizeof(float);   // partial tiles of the fused output layer (narrow nets: larger)
+  return acts > head ? acts : head;
 }
 
 static bool fusable(const PqlMlpDesc* d, int* buf_ld_out) {
@@ -553,8 +555,21 @@ extern "C" int pqlk_mlp_pack(const PqlMlpDesc* d, const float* params, float* pa
   return PQLK_OK;
 }
 
+struct FusedHead {   // output layer to run inside the fused launch (n = 0: none)
+  int n, epi;
+  const float* draw;
+  float noise_std, noise_clip;
+  float* out2;
+  int64_t ld_out2;
+};
+
+// the output layer can ride along when it is at most one 32-column tile wide and the last hidden width is a multiple of 32
+static bool head_fusable(const PqlMlpDesc* d) {
+  return d->n_layers >= 2 && d->dims[d->n_layers] <= 32 && d->dims[d->n_layers - 1] % 32 == 0;
+}
+
 static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const float* packed, const float* x, int64_t ldx,
-                               int64_t b, float* acts, int stash_all, hipStream_t st) {
+                               int64_t b, float* acts, int stash_all, hipStream_t st, const FusedHead* head = nullptr) {
   FusedP p = {};
   int buf_ld = 0;
   if (!fusable(d, &buf_ld)) return PQLK_E_UNSUPPORTED;
@@ -573,6 +588,15 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
     pqlk_mlp_act_offset(d, b, 0, l, &a_off, &a_ld);
     p.b_off[l] = b_off; p.p_off[l] = p_off; p.a_off[l] = a_off;
     p_off += (int64_t)d->dims[l + 1] * pqlk_ld(d->dims[l]);
+  }
+  if (head && head->n > 0) {
+    const int L = d->n_layers;
+    int64_t w_off, b_off, a_off, a_ld;
+    pqlk_mlp_layer_offsets(d, L - 1, &w_off, &b_off);
+    pqlk_mlp_act_offset(d, b, 0, L - 1, &a_off, &a_ld);
+    p.head_n = head->n; p.head_epi = head->epi; p.head_ld = (int)a_ld; p.ld_out2 = (int)head->ld_out2;
+    p.head_w_off = w_off; p.head_b_off = b_off; p.head_a_off = a_off;
+    p.draw = head->draw; p.out2 = head->out2; p.noise_std = head->noise_std; p.noise_clip = head->noise_clip;
   }
   // rows per block: 64 (R = 2) when no hidden layer is wider than 512 (two output tiles per wave, 132 KB of LDS) and the
   // halved grid still fills the 256 CUs about as well -- cost model: rounds x rows per block, 32-row blocks ~15 % less
@@ -625,9 +649,15 @@ extern "C" int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const 
   int l_first = 0;
   if (packed && fusable(d, nullptr)) {  // all hidden layers in one launch, activations resident in LDS
     PQLK_REQUIRE(pqlk_aligned16(packed), PQLK_E_ALIGN);
-    rc = launch_fused_hidden(d, params, packed, x, ldx, b, acts, stash_all ? 1 : 0, pqlk_s(stream));
+    FusedHead head = {};
+    static const bool no_head = getenv("PQLK_NO_FUSED_HEAD") != nullptr;   // tuning / A-B switch
+    if (head_fusable(d) && !no_head) {   // ... and the output layer too
+      head.n = d->dims[L]; head.epi = out_act; head.draw = draw; head.noise_std = noise_std; head.noise_clip = noise_clip;
+      head.out2 = out2; head.ld_out2 = ld_out2;
+    }
+    rc = launch_fused_hidden(d, params, packed, x, ldx, b, acts, stash_all ? 1 : 0, pqlk_s(stream), &head);
     if (rc) return rc;
-    l_first = L - 1;
+    l_first = head.n > 0 ? L : L - 1;
   }
   for (int l = l_first; l < L; ++l) {
     int64_t w_off, b_off, a_off, a_ld;

@@ -161,7 +161,10 @@ def test_mlp_backward_is_linear_and_forward_deterministic_at_batch_32768(dev):
     a1 = mlp_forward_raw(lay, arena, x, L.ACT_NONE, packed=pk, stash_all=True)
     a2 = mlp_forward_raw(lay, arena, x, L.ACT_NONE, packed=pk, stash_all=True)
     a3 = mlp_forward_raw(lay, arena, x, L.ACT_NONE)
-    assert torch.equal(a1, a2) and torch.equal(a1, a3)
+    assert torch.equal(a1, a2)
+    n_out = 2 * B * lay.ld_out                       # the output block sits at the end of the stash
+    assert torch.equal(a1[:-n_out], a3[:-n_out])     # hidden layers: fused == per-layer, bitwise
+    torch.testing.assert_close(a1[-n_out:], a3[-n_out:], rtol=2e-6, atol=2e-6)   # fused output layer: split reduction (reassociation)
     splits = default_splits(B)
     ws = torch.empty(lay.bwd_ws_floats(B, splits), device=dev)
 

@@ -437,9 +437,15 @@ def test_fused_forward_equals_per_layer_path(dev, dims, nets, B):
     pk.refresh(arena)
     a_ref = mlp_forward_raw(lay, arena, x, L.ACT_NONE)
     a_fused = mlp_forward_raw(lay, arena, x, L.ACT_NONE, packed=pk, stash_all=True)
-    assert torch.equal(a_ref, a_fused)
+    # hidden stashes: bit-identical.  Output layer: when it rides inside the fused launch (<= 32 outputs) its reduction is
+    # split over the 8 waves, i.e. a reassociation of the same products -> 1e-6 relative to the row's magnitude
+    o_ref, o_fused = output_view(lay, a_ref, B), output_view(lay, a_fused, B)
+    n_hidden_floats = a_ref.numel() - o_ref.numel()
+    assert torch.equal(a_ref[:n_hidden_floats], a_fused[:n_hidden_floats])
+    torch.testing.assert_close(o_fused, o_ref, rtol=2e-6, atol=2e-6)
+    assert torch.equal(o_fused[:, :, dims[-1]:], o_ref[:, :, dims[-1]:])          # pad columns are zero in both
     a_inf = mlp_forward_raw(lay, arena, x, L.ACT_NONE, packed=pk, stash_all=False)   # inference: only the tail is stashed
-    assert torch.equal(output_view(lay, a_inf, B), output_view(lay, a_ref, B))
+    assert torch.equal(output_view(lay, a_inf, B), o_fused)
 
 
 def test_fused_path_is_declined_for_unsupported_widths(dev):
