@@ -170,9 +170,11 @@ int pqlk_mlp_pack(const PqlMlpDesc* d, const float* params, float* packed, pqlk_
  * If out2 != NULL (n_nets must be 1) the final output is ALSO written to out2 with row stride ld_out2
  * (used to drop the actor's action into the action columns of a critic input: torch.cat for free).
  * packed != NULL (from pqlk_mlp_pack of the SAME params) selects the fused path: all hidden layers in one launch with
- * the activations of a 32-row tile resident in LDS; results are identical to the per-layer path (same accumulation
- * order).  stash_all = 0 on that path skips the HBM write of all but the last hidden layer (inference-only chains);
- * backward needs stash_all = 1.  On the fused path columns [dims[0], ldx) of x are IGNORED (masked to zero while the
+ * the activations of a 32- or 64-row tile resident in LDS; hidden activations are identical to the per-layer path (same
+ * accumulation order).  An output layer of at most 32 columns runs inside the same launch with its reduction split over
+ * the block's waves (a reassociation of the same products: ~1e-7 relative to the per-layer result).
+ * stash_all = 0 on that path writes only what a forward-only caller needs: the output block, plus the last hidden layer
+ * when the output layer is NOT fused; the other activation blocks are left untouched.  Backward needs stash_all = 1.  On the fused path columns [dims[0], ldx) of x are IGNORED (masked to zero while the
  * tile is staged), so x may alias a wider matrix; the per-layer path requires them to be zero. */
 int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const float* packed, int32_t stash_all,
                      const float* x, int64_t ldx, int64_t b,

@@ -337,7 +337,9 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
     // layer l's output goes to HBM either from its own epilogue (last hidden layer, ragged tiles) or from the next
     // layer's main loop (deferred: full tiles of a stashing forward)
     const bool defer = p.stash_all && full_tile;
-    float* gout = (last || (p.stash_all && !full_tile)) ? p.acts + p.a_off[l] + (long long)net * p.B * N : nullptr;
+    // (a forward-only call whose output layer is fused needs no HBM copy of the last hidden layer at all)
+    const bool keep_last = last && (p.stash_all || p.head_n == 0);
+    float* gout = (keep_last || (p.stash_all && !full_tile)) ? p.acts + p.a_off[l] + (long long)net * p.B * N : nullptr;
     float* gprev = (defer && l > 0) ? p.acts + p.a_off[l - 1] + (long long)net * p.B * p.dims[l] : nullptr;
     const int nprev4 = p.dims[l] >> 2;
     const float4* packed_n = last ? nullptr : packed_net + (p.p_off[l + 1] >> 2);
