@@ -7,9 +7,18 @@
 #pragma once
 #include "pqlk_common.h"
 
+typedef float narrow_acc_t __attribute__((ext_vector_type(16)));
+
+// element e of the NA partial accumulators of one tile, summed pairwise
+template <int NA>
+__device__ __forceinline__ float fold_acc(const narrow_acc_t (&a)[NA], int e) {
+  if (NA == 4) return (a[0][e] + a[1][e]) + (a[2 % NA][e] + a[3 % NA][e]);
+  return a[0][e] + a[1 % NA][e];
+}
+
 template <int NT, int EPI, int D>
 __global__ __launch_bounds__(64) void k_fwd_narrow(GemmP p) {
-  typedef float acc_t __attribute__((ext_vector_type(16)));
+  typedef narrow_acc_t acc_t;
   // D = ring depth in reduction steps of 8 (K8 is a multiple of D: straight-line refills, counted waits).  One wave per SIMD
   // and nothing else to hide latency behind: the loop is bound by (memory latency) / D per step, so the launcher picks the
   // deepest ring that divides K8 and fits the registers.
@@ -97,7 +106,7 @@ __global__ __launch_bounds__(64) void k_fwd_narrow(GemmP p) {
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int e = 4 * q + u;
-            const float dot = NA == 4 ? (acc[j][0][e] + acc[j][1][e]) + (acc[j][2 % NA][e] + acc[j][3 % NA][e]) : acc[j][0][e] + acc[j][1][e];
+            const float dot = fold_acc<NA>(acc[j], e);
             float x = dot + bb[u];
             if (EPI == EPI_TANH) x = tanhf(x);
             else if (EPI == EPI_TANH_NOISE) {
@@ -124,7 +133,7 @@ __global__ __launch_bounds__(64) void k_fwd_narrow(GemmP p) {
         float x = 0.f;   // pad column
         if (c < p.N) {
           const int e = 4 * q + u;
-          const float dot = NA == 4 ? (acc[j][0][e] + acc[j][1][e]) + (acc[j][2 % NA][e] + acc[j][3 % NA][e]) : acc[j][0][e] + acc[j][1][e];
+          const float dot = fold_acc<NA>(acc[j], e);
           x = dot + (bias ? bias[c] : 0.f);
           if (EPI == EPI_TANH) x = tanhf(x);
           else if (EPI == EPI_TANH_NOISE) {
