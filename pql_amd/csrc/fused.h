@@ -306,27 +306,49 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
                          lane);
   float4* out4 = reinterpret_cast<float4*>(fsm);
   const int bias4 = 32 * R * buf_ld4;   // float4 offset of the bias table: layer l at bias4 + l * (buf_ld4 - 1)
-  for (int l = 0; l < p.n_hidden; ++l) {
-    const float4* src = reinterpret_cast<const float4*>(p.params + (long long)net * p.net_stride + p.b_off[l]);
-    for (int i = tid; i < (p.dims[l + 1] >> 2); i += 64 * NW) out4[bias4 + l * (buf_ld4 - 1) + i] = src[i];
-  }
-  {  // stage the input tile (rows past B are zero-filled)
-    const int k0 = (p.dims[0] + 31) & ~31, cpr = k0 >> 2, w = p.dims[0];
-    for (int i = tid; i < 32 * R * cpr; i += 64 * NW) {
-      const int row = i / cpr, c4 = i % cpr;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row0 + row < p.B) v = *reinterpret_cast<const float4*>(p.X + (long long)(row0 + row) * p.ldx + 4 * c4);
-      // columns past the logical input width are forced to zero here, so X may be a wider matrix whose extra columns
-      // hold something else (the target actor reads its observations straight out of the critic's [obs | action] tile)
-      const int c = 4 * c4;
-      if (c + 3 >= w) {
-        if (c >= w) v.x = 0.f;
-        if (c + 1 >= w) v.y = 0.f;
-        if (c + 2 >= w) v.z = 0.f;
-        v.w = 0.f;
-      }
-      out4[row * buf_ld4 + c4] = v;
+  // Staging: every global load of the prologue (bias rows, then the input tile four quads at a time) is issued before
+  // the LDS stores that consume it.  One load -> one store per iteration exposes a full memory latency each time, and
+  // every block of the grid sits in this prologue at the same moment.
+  {
+    float4 bv[PQLK_MAX_LAYERS];   // hidden widths <= 1024 -> at most one float4 of each layer's bias per thread
+#pragma unroll
+    for (int l = 0; l < PQLK_MAX_LAYERS; ++l) {
+      bv[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (l < p.n_hidden && tid < (p.dims[l + 1] >> 2))
+        bv[l] = reinterpret_cast<const float4*>(p.params + (long long)net * p.net_stride + p.b_off[l])[tid];
     }
+    const int k0 = (p.dims[0] + 31) & ~31, cpr = k0 >> 2, w = p.dims[0], total = 32 * R * cpr;
+    // columns past the logical input width are forced to zero, so X may be a wider matrix whose extra columns hold
+    // something else (the target actor reads its observations straight out of the critic's [obs | action] tile);
+    // rows past B are zero-filled
+    for (int i0 = tid; i0 < total; i0 += 4 * 64 * NW) {
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 64 * NW;
+        const int row = i / cpr, c4 = i - row * cpr;
+        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < total && row0 + row < p.B) v[u] = *reinterpret_cast<const float4*>(p.X + (long long)(row0 + row) * p.ldx + 4 * c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * 64 * NW;
+        if (i < total) {
+          const int row = i / cpr, c4 = i - row * cpr, c = 4 * c4;
+          float4 x = v[u];
+          if (c + 3 >= w) {
+            if (c >= w) x.x = 0.f;
+            if (c + 1 >= w) x.y = 0.f;
+            if (c + 2 >= w) x.z = 0.f;
+            x.w = 0.f;
+          }
+          out4[row * buf_ld4 + c4] = x;
+        }
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < PQLK_MAX_LAYERS; ++l)
+      if (l < p.n_hidden && tid < (p.dims[l + 1] >> 2)) out4[bias4 + l * (buf_ld4 - 1) + tid] = bv[l];
   }
   __syncthreads();
   for (int l = 0; l < p.n_hidden; ++l) {
