@@ -17,6 +17,7 @@
 // index kk = 8*k8 + 4*h + t.  A and B use the same map, so any such bijection is a valid dot product;
 // this one lets k-contiguous operands be fetched with one ds_read_b128 per four MFMAs.
 #include <cstdlib>
+#include <type_traits>
 #include "pqlk_common.h"
 #include "skinny.h"
 #include "fused.h"
@@ -57,6 +58,11 @@ struct GemmP {
 #endif
 // row stride of a k-contiguous tile = KT + 4 floats (36 or 20: odd multiple of 4 -> conflict-free b128 reads)
 
+// Native 4-float vector for the register tiles: HIP's float4 is a struct whose copies lower to llvm.memcpy, and a memcpy
+// from global into a private object that a later iteration stores to LDS is not promoted to registers (the tiles of the
+// two-deep prefetch ended up in scratch memory).
+typedef float f4v __attribute__((ext_vector_type(4)));
+
 // ---- tile loaders: global -> registers -> LDS -------------------------------------------------
 // k-contiguous tile: ROWS rows x 32 floats.  Chunk c (16 B): row = c>>3, kc = c&7.
 template <int ROWS, int KT>
@@ -64,7 +70,7 @@ struct KcTile {
   static constexpr int CPR = KT / 4;            // 16-B chunks per row
   static constexpr int LD = KT + 4;
   static constexpr int CH = ROWS * CPR / 256;   // float4 chunks per thread
-  float4 v[CH];
+  f4v v[CH];
   __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int row_lim, int k0, int k_lim,
                                        int tid) {
 #pragma unroll
@@ -73,16 +79,25 @@ struct KcTile {
       const int row = row0 + c / CPR;
       const int k = k0 + ((c % CPR) << 2);
       if (row < row_lim && k < k_lim)
-        v[i] = *reinterpret_cast<const float4*>(base + (long long)row * ld + k);
+        v[i] = *reinterpret_cast<const f4v*>(base + (long long)row * ld + k);
       else
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = f4v{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  // interior tile: no bounds tests, so the loads are straight-line code and the compiler can keep a later tile's loads
+  // in flight behind a counted s_waitcnt vmcnt(N)
+  __device__ __forceinline__ void load_inner(const float* __restrict__ base, int ld, int row0, int k0, int tid) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = tid + 256 * i;
+      v[i] = *reinterpret_cast<const f4v*>(base + (long long)(row0 + c / CPR) * ld + k0 + ((c % CPR) << 2));
     }
   }
   __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = tid + 256 * i;
-      *reinterpret_cast<float4*>(lds + (c / CPR) * LD + ((c % CPR) << 2)) = v[i];
+      *reinterpret_cast<f4v*>(lds + (c / CPR) * LD + ((c % CPR) << 2)) = v[i];
     }
   }
 };
@@ -93,7 +108,7 @@ struct RrTile {
   static constexpr int CPR = COLS / 4;
   static constexpr int CH = KT * CPR / 256;
   static constexpr int LD = COLS + 4;
-  float4 v[CH];
+  f4v v[CH];
   __device__ __forceinline__ void load(const float* __restrict__ base, int ld, int row0, int row_lim, int col0, int col_lim,
                                        int tid) {
 #pragma unroll
@@ -102,16 +117,23 @@ struct RrTile {
       const int row = row0 + c / CPR;
       const int col = col0 + ((c % CPR) << 2);
       if (row < row_lim && col < col_lim)
-        v[i] = *reinterpret_cast<const float4*>(base + (long long)row * ld + col);
+        v[i] = *reinterpret_cast<const f4v*>(base + (long long)row * ld + col);
       else
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = f4v{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  __device__ __forceinline__ void load_inner(const float* __restrict__ base, int ld, int row0, int col0, int tid) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = tid + 256 * i;
+      v[i] = *reinterpret_cast<const f4v*>(base + (long long)(row0 + c / CPR) * ld + col0 + ((c % CPR) << 2));
     }
   }
   __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
       const int c = tid + 256 * i;
-      *reinterpret_cast<float4*>(lds + (c / CPR) * LD + ((c % CPR) << 2)) = v[i];
+      *reinterpret_cast<f4v*>(lds + (c / CPR) * LD + ((c % CPR) << 2)) = v[i];
     }
   }
 };
@@ -128,7 +150,7 @@ struct Smem {
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
 template <int MODE, int BM, int BN, int EPI, int KT>
-__global__ __launch_bounds__(256) void k_gemm(GemmP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm(GemmP p) {   // exactly 2 waves per SIMD: the register allocator otherwise aims for 4 and spills the second tile set
   constexpr int WM = BM / 2, WN = BN / 2;  // per-wave patch
   constexpr int MI = WM / 32, NJ = WN / 32;
   constexpr int KC_LD = KT + 4;
@@ -164,6 +186,13 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
 
   float dbacc = 0.f;  // DW: column sum of dY for row tid of this block's dW tile (blockIdx.x == 0 only)
 
+  // two register tile sets of the interior main loop (function scope: declared inside the group loop they are kept in
+  // scratch memory instead of registers)
+  KcTile<BM, KT> a_kc0, a_kc1;
+  RrTile<BM, KT> a_rr0, a_rr1;
+  KcTile<BN, KT> b_kc0, b_kc1;
+  RrTile<BN, KT> b_rr0, b_rr1;
+
   for (int g = g0; g < g1; ++g) {
     const float* A = p.A + (long long)g * p.sA;
     const float* B = p.B + (long long)g * p.sB;
@@ -176,7 +205,112 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
     const int nk = (kend - kbeg + KT - 1) / KT;
     if (nk <= 0) continue;
 
-    // register prefetch buffers
+    // one LDS stage -> MFMAs
+    auto compute = [&](int kt, int stage) {
+      const float* sa = smem + stage * S::STAGE;
+      const float* sb = sa + S::A_FLOATS;
+
+      if (MODE == MODE_DW && blockIdx.x == 0 && tid < BM) {
+#pragma unroll 8
+        for (int rr = 0; rr < KT; ++rr) dbacc += sa[rr * (BM + 4) + tid];
+      }
+
+#pragma unroll
+      for (int k8 = 0; k8 < KT / 8; ++k8) {
+        float af[MI][4], bf[NJ][4];
+#if defined(PQLK_PROBE_NOLDS)   // tuning probe only: operands from registers, pure MFMA issue rate
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { af[i][t] = __int_as_float(lane + kt + t + i); asm volatile("" : "+v"(af[i][t])); }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) { bf[j][t] = __int_as_float(lane - kt + t + j); asm volatile("" : "+v"(bf[j][t])); }
+#else
+        (void)kt;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          if (MODE == MODE_DW) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) af[i][t] = sa[(8 * k8 + 4 * h + t) * (BM + 4) + wm + 32 * i + r];
+          } else {
+            const float4 v = *reinterpret_cast<const float4*>(sa + (wm + 32 * i + r) * KC_LD + 8 * k8 + 4 * h);
+            af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          if (MODE == MODE_FWD) {
+            const float4 v = *reinterpret_cast<const float4*>(sb + (wn + 32 * j + r) * KC_LD + 8 * k8 + 4 * h);
+            bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bf[j][t] = sb[(8 * k8 + 4 * h + t) * (BN + 4) + wn + 32 * j + r];
+          }
+        }
+#endif
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][t], af[i][t], acc[i][j], 0, 0, 0);
+      }
+    };
+
+#if !defined(PQLK_PROBE_NOLOAD) && !defined(PQLK_NO_PF2)
+    // ---- interior blocks: every tile is full, so the loads need no bounds tests, are straight-line code, and can run TWO
+    // tiles ahead: tile kt+2 is requested at the top of iteration kt into the register set that tile kt vacated, tile kt+1
+    // (requested one iteration earlier) is moved to LDS at the bottom behind a counted wait.  With one tile of lead
+    // (32 MFMAs per wave, ~1 us) the wait before the LDS store regularly outlasts the MFMAs; two tiles cover an L2 / HBM
+    // round trip.  The tail re-requests the last tile instead of branching (a branch would void the counted waits).
+    bool inner = (m0 + BM <= p.M) && ((kend - kbeg) % KT == 0) && (nk % 2 == 0);
+    if (MODE == MODE_FWD) inner = inner && (n0 + BN <= p.N);
+    if (MODE == MODE_DX) inner = inner && (n0 + BN <= p.ldb) && (kend <= p.lda);
+    if (MODE == MODE_DW) inner = inner && (m0 + BM <= p.lda) && (n0 + BN <= p.ldb);
+    if (inner) {
+      // (plain macros, not lambdas taking the tiles by reference: those keep the tiles in scratch memory)
+#define PQLK_GL(KTILE, Q)                                                                                                      \
+  do {                                                                                                                         \
+    const int k0_ = kbeg + (KTILE) * KT;                                                                                       \
+    if (MODE == MODE_FWD) { a_kc##Q.load_inner(A, p.lda, m0, k0_, tid); b_kc##Q.load_inner(B, p.ldb, n0, k0_, tid); }          \
+    else if (MODE == MODE_DX) { a_kc##Q.load_inner(A, p.lda, m0, k0_, tid); b_rr##Q.load_inner(B, p.ldb, k0_, n0, tid); }      \
+    else { a_rr##Q.load_inner(A, p.lda, k0_, m0, tid); b_rr##Q.load_inner(B, p.ldb, k0_, n0, tid); }                           \
+  } while (0)
+#define PQLK_SS(STG, Q)                                                                                                        \
+  do {                                                                                                                         \
+    float* sa_ = smem + (STG) * S::STAGE;                                                                                      \
+    float* sb_ = sa_ + S::A_FLOATS;                                                                                            \
+    if (MODE == MODE_FWD) { a_kc##Q.store(sa_, tid); b_kc##Q.store(sb_, tid); }                                                \
+    else if (MODE == MODE_DX) { a_kc##Q.store(sa_, tid); b_rr##Q.store(sb_, tid); }                                            \
+    else { a_rr##Q.store(sa_, tid); b_rr##Q.store(sb_, tid); }                                                                 \
+  } while (0)
+      PQLK_GL(0, 0);
+      __syncthreads();  // previous group's last stage may still be in use
+      PQLK_SS(0, 0);
+      PQLK_GL(1, 1);
+      __syncthreads();
+      for (int kt = 0; kt < nk; kt += 2) {
+        PQLK_GL(min(kt + 2, nk - 1), 0);
+        __builtin_amdgcn_sched_barrier(0);   // keep the requests at the top of the iteration
+        compute(kt, 0);
+        PQLK_SS(1, 1);
+        __syncthreads();
+        PQLK_GL(min(kt + 3, nk - 1), 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(kt + 1, 1);
+        PQLK_SS(0, 0);
+        __syncthreads();
+      }
+#undef PQLK_GL
+#undef PQLK_SS
+      continue;
+    }
+#endif
+
+    // ---- generic path (edge tiles): bounds-tested loads, one tile of lead
     KcTile<BM, KT> a_kc;
     RrTile<BM, KT> a_rr;
     KcTile<BN, KT> b_kc;
@@ -222,57 +356,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmP p) {
       const int stage = kt & 1;
       if (kt + 1 < nk) gload(kt + 1);
 #endif
-      const float* sa = smem + stage * S::STAGE;
-      const float* sb = sa + S::A_FLOATS;
-
-      if (MODE == MODE_DW && blockIdx.x == 0 && tid < BM) {
-#pragma unroll 8
-        for (int rr = 0; rr < KT; ++rr) dbacc += sa[rr * (BM + 4) + tid];
-      }
-
-#pragma unroll
-      for (int k8 = 0; k8 < KT / 8; ++k8) {
-        float af[MI][4], bf[NJ][4];
-#if defined(PQLK_PROBE_NOLDS)   // tuning probe only: operands from registers, pure MFMA issue rate
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) { af[i][t] = __int_as_float(lane + kt + t + i); asm volatile("" : "+v"(af[i][t])); }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) { bf[j][t] = __int_as_float(lane - kt + t + j); asm volatile("" : "+v"(bf[j][t])); }
-#else
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          if (MODE == MODE_DW) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) af[i][t] = sa[(8 * k8 + 4 * h + t) * (BM + 4) + wm + 32 * i + r];
-          } else {
-            const float4 v = *reinterpret_cast<const float4*>(sa + (wm + 32 * i + r) * KC_LD + 8 * k8 + 4 * h);
-            af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          if (MODE == MODE_FWD) {
-            const float4 v = *reinterpret_cast<const float4*>(sb + (wn + 32 * j + r) * KC_LD + 8 * k8 + 4 * h);
-            bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
-          } else {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) bf[j][t] = sb[(8 * k8 + 4 * h + t) * (BN + 4) + wn + 32 * j + r];
-          }
-        }
-#endif
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-          for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[j][t], af[i][t], acc[i][j], 0, 0, 0);
-      }
-
+      compute(kt, stage);
 #if !defined(PQLK_PROBE_NOLOAD)
       if (kt + 1 < nk) sstore(stage ^ 1);
       __syncthreads();
