@@ -95,22 +95,52 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
   }
   __syncthreads();
   const float coef = s_coef, step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float gi = g[i] * coef;
-    float pi = p[i] * c.lr_wd_decay;                 // p.mul_(1 - lr*wd)
-    float mi = m[i];
-    mi = mi + c.w1 * (gi - mi);                      // m.lerp_(g, 1-b1)
-    float vi = v[i] * c.b2 + (c.one_m_b2 * gi) * gi; // v.mul_(b2).addcmul_(g, g, 1-b2)
+  // one parameter: the arithmetic of torch's AdamW foreach kernels, op for op (per element, so the 16-B path below
+  // produces the same bits as the scalar one)
+  auto upd = [&](float gi, float& pi, float& mi, float& vi, float& ti) {
+    gi = gi * coef;
+    pi = pi * c.lr_wd_decay;                     // p.mul_(1 - lr*wd)
+    mi = mi + c.w1 * (gi - mi);                  // m.lerp_(g, 1-b1)
+    vi = vi * c.b2 + (c.one_m_b2 * gi) * gi;     // v.mul_(b2).addcmul_(g, g, 1-b2)
     const float denom = sqrtf(vi) / bc2_sqrt + c.eps;
-    pi = pi + (-step_size) * (mi / denom);           // p.addcdiv_(m, denom, -lr/bc1)
-    p[i] = pi;
-    m[i] = mi;
-    v[i] = vi;
-    float ti = 0.f;
-    if (target) {
-      ti = pi * c.tau + target[i] * c.one_m_tau;  // soft_update
-      target[i] = ti;
+    pi = pi + (-step_size) * (mi / denom);       // p.addcdiv_(m, denom, -lr/bc1)
+    ti = target ? pi * c.tau + ti * c.one_m_tau : 0.f;   // soft_update
+  };
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  auto al16 = [](const void* q) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0; };
+  const bool vec = al16(p) && al16(g) && al16(m) && al16(v) && (!target || al16(target));
+  const int64_t n4 = vec ? (n >> 2) : 0;
+  // 16-B path: four consecutive parameters per thread.  Arena blocks start on multiples of 32 floats and rows are
+  // multiples of 32 long, so an aligned quad never straddles a packed block and maps to ONE 16-B quad of the
+  // fragment-ordered copy (j = k & 3 runs over the quad): the re-pack is a 16-B store too.
+  for (int64_t q4 = (int64_t)blockIdx.x * 256 + threadIdx.x; q4 < n4; q4 += (int64_t)gridDim.x * 256) {
+    const int64_t i = q4 << 2;
+    const f4 g4 = reinterpret_cast<const f4*>(g)[q4];
+    f4 p4 = reinterpret_cast<f4*>(p)[q4], m4 = reinterpret_cast<f4*>(m)[q4], v4 = reinterpret_cast<f4*>(v)[q4];
+    f4 t4 = target ? reinterpret_cast<f4*>(target)[q4] : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float pi = p4[u], mi = m4[u], vi = v4[u], ti = t4[u];
+      upd(g4[u], pi, mi, vi, ti);
+      p4[u] = pi; m4[u] = mi; v4[u] = vi; t4[u] = ti;
     }
+    reinterpret_cast<f4*>(p)[q4] = p4;
+    reinterpret_cast<f4*>(m)[q4] = m4;
+    reinterpret_cast<f4*>(v)[q4] = v4;
+    if (target) reinterpret_cast<f4*>(target)[q4] = t4;
+    if (ps.n > 0) {
+      const long long q = packed_index(ps, i);
+      if (q >= 0) {
+        *reinterpret_cast<f4*>(ps.packed_p + q) = p4;
+        if (target && ps.packed_t) *reinterpret_cast<f4*>(ps.packed_t + q) = t4;
+      }
+    }
+  }
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {   // tail / unaligned
+    float pi = p[i], mi = m[i], vi = v[i], ti = target ? target[i] : 0.f;
+    upd(g[i], pi, mi, vi, ti);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (target) target[i] = ti;
     if (ps.n > 0) {
       const long long q = packed_index(ps, i);
       if (q >= 0) {
@@ -146,7 +176,7 @@ static int adamw_impl(float* p, float* g, float* m, float* v, float* target, int
   c.lr = (double)lr;
   c.b1d = (double)b1;
   c.b2d = (double)b2;
-  int blocks2 = (int)((n + 255) / 256);
+  int blocks2 = (int)(((n + 3) / 4 + 255) / 256);   // one 16-B quad per thread
   if (blocks2 > 2048) blocks2 = 2048;
   hipLaunchKernelGGL(k_adamw, dim3(blocks2), dim3(256), 0, pqlk_s(stream), p, g, m, v, target, n, scratch, blocks, c, step_dev,
                      gnorm_out, ps);
