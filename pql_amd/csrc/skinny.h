@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
   static_assert(CLS == 16 || CLS == 4, "column-lane count");
   __shared__ float dy_lds[ROWS][SKINNY_MAX_N + 1];
   __shared__ __attribute__((aligned(16))) float red[8][RLS][CLS][4];   // 32 KB
+  __shared__ float db_part[16][16];
   const int g = blockIdx.z, split = blockIdx.y;
   const int cl = threadIdx.x & (CLS - 1), rl = threadIdx.x >> CSH;
   const int col = blockIdx.x * (4 * CLS) + 4 * cl;
@@ -155,22 +156,56 @@ __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
   for (int n = 0; n < SKINNY_MAX_N; ++n) acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
   float dbacc = 0.f;   // block column 0 only: lanes tid < N each own one bias column over this block's rows
   const bool col_ok = col < p.K;
+  const bool dy_vec = (p.N & 3) == 0 && (p.ldy & 3) == 0;
   for (int m0 = m_beg; m0 < m_end; m0 += ROWS) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < ROWS * p.N; i += 256) {
-      const int r = i / p.N, n = i % p.N;
-      dy_lds[r][n] = (m0 + r < m_end) ? dY[(long long)(m0 + r) * p.ldy + n] : 0.f;
+    // wide heads (dy_vec): the first batch of X rows is requested BEFORE dY is staged, so the two round trips overlap
+    // instead of adding up (16.5 -> 11.5 us at N = 16; the scalar head N = 1 measured 0.8 us slower that way)
+    float4 hv[4];
+    if (dy_vec) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int r = rl + RLS * v;
+        hv[v] = (col_ok && m0 + r < m_end) ? *reinterpret_cast<const float4*>(X + (long long)(m0 + r) * p.ldx + col)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
+    __syncthreads();
+#if !defined(PQLK_SKDW_NOSTAGE)   // tuning probe only
+    if (dy_vec) {   // 16-B loads, all of a thread's quads requested before the first LDS store
+      const int qn = p.N >> 2;
+      constexpr int QMAX = ROWS * (SKINNY_MAX_N / 4) / 256;
+      float4 q[QMAX];
+#pragma unroll
+      for (int t = 0; t < QMAX; ++t) {
+        const int i = threadIdx.x + 256 * t, r = i / qn, c4 = i - r * qn;
+        q[t] = (i < ROWS * qn && m0 + r < m_end) ? *reinterpret_cast<const float4*>(dY + (long long)(m0 + r) * p.ldy + 4 * c4)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int t = 0; t < QMAX; ++t) {
+        const int i = threadIdx.x + 256 * t, r = i / qn, c4 = i - r * qn;
+        if (i < ROWS * qn) {
+          dy_lds[r][4 * c4] = q[t].x; dy_lds[r][4 * c4 + 1] = q[t].y; dy_lds[r][4 * c4 + 2] = q[t].z; dy_lds[r][4 * c4 + 3] = q[t].w;
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < ROWS * p.N; i += 256) {
+        const int r = i / p.N, n = i % p.N;
+        dy_lds[r][n] = (m0 + r < m_end) ? dY[(long long)(m0 + r) * p.ldy + n] : 0.f;
+      }
+    }
+#endif
     __syncthreads();
     // rows rl, rl + RLS, ... of this chunk, loads issued 4 at a time
 #pragma unroll
     for (int u = 0; u < ROWS / RLS; u += 4) {
-      float4 hv[4];
+      if (u > 0 || !dy_vec) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const int r = rl + RLS * (u + v);
-        hv[v] = (col_ok && m0 + r < m_end) ? *reinterpret_cast<const float4*>(X + (long long)(m0 + r) * p.ldx + col)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int v = 0; v < 4; ++v) {
+          const int r = rl + RLS * (u + v);
+          hv[v] = (col_ok && m0 + r < m_end) ? *reinterpret_cast<const float4*>(X + (long long)(m0 + r) * p.ldx + col)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
@@ -184,8 +219,18 @@ __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
         }
       }
     }
-    if (blockIdx.x == 0 && (int)threadIdx.x < p.N)   // bias gradient: one thread per output, rows in order
-      for (int r = 0; r < ROWS; ++r) dbacc += dy_lds[r][threadIdx.x];
+    if (blockIdx.x == 0) {   // bias gradient (block-uniform branch): 16 threads per output sum every 16th row, then a fixed fold
+      const int bn = threadIdx.x & 15, bpart = threadIdx.x >> 4;
+      float sb = 0.f;
+      if (bn < p.N)
+        for (int r = bpart; r < ROWS; r += 16) sb += dy_lds[r][bn];
+      db_part[bpart][bn] = sb;
+      __syncthreads();
+      if ((int)threadIdx.x < p.N) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dbacc += db_part[k][threadIdx.x];
+      }
+    }
   }
   float* dW = p.dW + (long long)g * p.sW + (long long)split * p.sSplit;
   // Fold the RLS row-lanes: eight outputs n at a time go to LDS, then ALL threads reduce -- P = 256 / (8 CLS) threads per
@@ -198,7 +243,11 @@ __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
   const int ocol = blockIdx.x * (4 * CLS) + 4 * oc;
 #pragma unroll
   for (int half = 0; half < SKINNY_MAX_N / 8; ++half) {
+#if defined(PQLK_SKDW_NOFOLD)   // tuning probe only
+    if (false) {
+#else
     if (8 * half < p.N) {  // block-uniform
+#endif
       __syncthreads();
 #pragma unroll
       for (int nn = 0; nn < 8; ++nn)
