@@ -475,12 +475,11 @@ static int launch_gemm(GemmP p, int gz, hipStream_t st) {
   constexpr int KT = PQLK_KT;
   using S = Smem<MODE, BM, BN, KT>;
   const size_t shmem = (size_t)2 * S::STAGE * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PqlkPerDeviceOnce attr_once;
+  if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, BM, BN, EPI, KT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return -(int)e;
-    attr_set = true;
   }
   int ncols = (MODE == MODE_DW) ? p.N : p.ncols_store;
   p.n_base = 0;
@@ -696,15 +695,14 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
     if (forced == 32) R = 1;
     if (forced == 64) R = 2;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PqlkPerDeviceOnce attr_once;
+  if (attr_once.need()) {
     const void* ks[3] = {reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 2>), reinterpret_cast<const void*>(&k_mlp_fwd_fused<2, 2>),
                          reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 4>)};
     for (const void* k : ks) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return -(int)e;
     }
-    attr_set = true;
   }
   const size_t shmem = fused_lds_bytes(d, buf_ld, R);
   const dim3 grid((unsigned)(((b + 32 * R - 1) / (32 * R)) * d->n_nets)), block(64 * FUSED_NW);

@@ -290,14 +290,13 @@ static bool dx_slice_ok(const GemmP& p) {
 
 static int launch_dx_slice(const GemmP& p, hipStream_t st) {
   const size_t shmem = dx_slice_lds(p);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static PqlkPerDeviceOnce attr_once;
+  if (attr_once.need()) {
     for (const void* k : {reinterpret_cast<const void*>(&k_dx_slice<16>), reinterpret_cast<const void*>(&k_dx_slice<4>),
                           reinterpret_cast<const void*>(&k_dx_slice<1>)}) {
       hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return -(int)e;
     }
-    attr_set = true;
   }
   const int K8 = p.groups * p.K / 32;   // reduction steps of 8 per wave
   const dim3 grid((unsigned)((p.M + 31) / 32)), block(256);

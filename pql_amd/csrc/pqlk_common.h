@@ -48,6 +48,19 @@ __host__ __device__ static inline RecLayout rec_layout(int O, int A) {
   return L;
 }
 
+// "have I raised this kernel's dynamic-LDS limit on the CURRENT device yet?"  hipFuncSetAttribute acts on the current
+// device only, and one process may drive several (sim on GPU 0, learners on GPU 1): the flag is per device.
+struct PqlkPerDeviceOnce {
+  bool done[64] = {};
+  bool need() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+  }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -283,12 +283,11 @@ static int launch_skinny_fwd(const SkinnyP& p, int groups, hipStream_t st) {
   int blocks = (p.M + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   const size_t sh = (size_t)p.N * p.K * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static PqlkPerDeviceOnce attr_once;
+  if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skinny_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        SKINNY_MAX_N * SKINNY_MAX_K * 4);
     if (e != hipSuccess) return -(int)e;
-    attr = true;
   }
   hipLaunchKernelGGL(k_skinny_fwd, dim3(blocks, groups), dim3(256), sh, st, p);
   PQLK_LAUNCH_CHECK();
@@ -299,12 +298,11 @@ static int launch_skinny_dx(const SkinnyP& p, int groups, hipStream_t st) {
   int blocks = (p.M + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   const size_t sh = (size_t)p.N * p.K * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
+  static PqlkPerDeviceOnce attr_once;
+  if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skinny_dx), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        SKINNY_MAX_N * SKINNY_MAX_K * 4);
     if (e != hipSuccess) return -(int)e;
-    attr = true;
   }
   hipLaunchKernelGGL(k_skinny_dx, dim3(blocks, groups), dim3(256), sh, st, p);
   PQLK_LAUNCH_CHECK();
