@@ -615,3 +615,70 @@ def test_dx_slice_kernel_equals_full_input_gradient(dev, O, A, hidden, B):
     scale = float(want.abs().max())
     np.testing.assert_allclose(sl[:, :A].cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-6 * scale)
     assert torch.all(sl[:, A:] == 3.0)   # only the slice columns are written
+
+
+# --------------------------------------------------------------------------- shape sweep of the MLP path
+_SWEEP = [
+    # dims (in, hidden..., out), nets, B, fused?
+    ([104, 512, 512, 256, 1], 2, 1024, True),     # BASELINE critic: fused body + fused head, 128x128 tiles, interior prefetch
+    ([88, 512, 256, 128, 16], 1, 1000, True),     # actor, ragged batch
+    ([229, 512, 256, 128, 51], 2, 96, True),      # C51 head (two narrow tiles), tiny batch
+    ([60, 96, 64, 8], 1, 257, True),              # narrow layers: idle waves, short reductions
+    ([48, 100, 36, 12], 1, 130, False),           # widths not multiples of 32: per-layer path, edge tiles everywhere
+    ([17, 64, 33], 2, 513, True),                 # fused body, 33 outputs: narrow kernel with a ragged second tile
+    ([129, 1024, 512, 5], 1, 300, True),          # 1024-wide layer (four tiles per wave)
+    ([40, 32, 1], 2, 2049, True),                 # one tiny hidden layer, scalar head
+]
+
+
+@pytest.mark.parametrize("dims,nets,B,fused", _SWEEP)
+def test_mlp_shape_sweep_vs_oracle(dev, ref, dims, nets, B, fused):
+    """Forward (every stashed activation) and backward (parameter + input gradients) of arbitrary MLP shapes against the
+    oracle's torch-CPU autograd: covers the fused / per-layer split, skinny / narrow / MFMA heads, interior and edge GEMM
+    tiles, ragged batches."""
+    from pql_amd import _lib as L
+    from pql_amd.models.mlp import ArenaLayout, PackedWeights, default_splits, mlp_forward_raw, output_view
+    lay = ArenaLayout(dims, nets)
+    arena = torch.zeros(lay.total, device=dev)
+    params = []
+    for n in range(nets):
+        net = []
+        for l in range(lay.n_layers):
+            bound = 1.0 / np.sqrt(dims[l])
+            w = T(dd.uniform((dims[l + 1], dims[l]), 300 * n + l, -bound, bound)); b = T(dd.uniform((dims[l + 1],), 300 * n + l + 60, -bound, bound))
+            lay.weight(arena, n, l).copy_(w); lay.bias(arena, n, l).copy_(b)
+            net += [w.clone().requires_grad_(True), b.clone().requires_grad_(True)]
+        params.append(net)
+    xc = T(dd.uniform((B, dims[0]), 9, -2, 2)).requires_grad_(True)
+    x = torch.zeros((B, lay.ld_in), device=dev); x[:, : dims[0]] = xc.detach().to(dev)
+    pk = PackedWeights(lay, dev)
+    assert (pk.tensor is not None) == fused
+    if fused:
+        pk.refresh(arena)
+    acts = mlp_forward_raw(lay, arena, x, L.ACT_NONE, packed=pk if fused else None, stash_all=True)
+    y = output_view(lay, acts, B)
+    outs = [ref.mlp_forward_ref(params[n], xc) for n in range(nets)]
+    for n in range(nets):
+        np.testing.assert_allclose(y[n, :, : dims[-1]].cpu().numpy(), outs[n].detach().numpy(), rtol=1e-5, atol=1e-5)
+        assert torch.all(y[n, :, dims[-1]:] == 0)
+    # backward of sum_n <y_n, w_n>
+    wts = [T(dd.uniform((B, dims[-1]), 70 + n, -1, 1)) for n in range(nets)]
+    dy = torch.zeros((nets, B, lay.ld_out), device=dev)
+    for n in range(nets):
+        dy[n, :, : dims[-1]] = wts[n].to(dev)
+    splits = default_splits(B)
+    grads = torch.empty_like(arena); dx = torch.empty((B, lay.ld_in), device=dev)
+    ws = torch.empty(lay.bwd_ws_floats(B, splits), device=dev)
+    L.check(L.lib.pqlk_mlp_backward(C.byref(lay.desc), L.ptr(arena), L.ptr(x), lay.ld_in, B, L.ptr(acts), L.ptr(dy), L.ptr(grads), splits,
+                                    L.ptr(dx), lay.ld_in, 0, 0, None, 0, L.ptr(ws), ws.numel(), L.stream(dev)))
+    loss = sum((outs[n] * wts[n]).sum() for n in range(nets))
+    gr = torch.autograd.grad(loss, [xc] + [p for net in params for p in net])
+    gx = gr[0].numpy()
+    np.testing.assert_allclose(dx[:, : dims[0]].cpu().numpy(), gx, rtol=1e-4, atol=2e-5 * (np.abs(gx).max() + 1e-12))
+    k = 1
+    for n in range(nets):
+        for l in range(lay.n_layers):
+            gw, gb = gr[k].numpy(), gr[k + 1].numpy(); k += 2
+            scale = np.abs(gw).max() + 1e-12
+            np.testing.assert_allclose(lay.weight(grads, n, l).cpu().numpy(), gw, rtol=1e-4, atol=2e-5 * scale, err_msg=f"dW net {n} layer {l}")
+            np.testing.assert_allclose(lay.bias(grads, n, l).cpu().numpy(), gb, rtol=1e-4, atol=2e-5 * max(scale, np.abs(gb).max()), err_msg=f"db net {n} layer {l}")
