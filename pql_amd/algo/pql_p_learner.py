@@ -12,6 +12,7 @@ learn()  (reference :47-64)  ->  one launch sequence
 from __future__ import annotations
 
 import contextlib
+import os
 import ctypes as C
 import time
 from copy import deepcopy
@@ -197,7 +198,9 @@ class PQLPLearner:
         torch.cuda.set_rng_state(rng, self.device)
         g = torch.cuda.CUDAGraph()
         g_post = None
-        if not self.dp:
+        # PQL_DP_GRAPH_COLLECTIVE=1 (opt-in, rehearsed with a 1-rank RCCL group only): capture the all-reduce inside ONE graph
+        # instead of splitting the step around an eager collective
+        if not self.dp or os.environ.get("PQL_DP_GRAPH_COLLECTIVE"):
             with torch.cuda.graph(g):
                 self._draw_and_step(ws)
         else:

@@ -15,6 +15,7 @@ is captured once into a hipGraph (through torch.cuda.CUDAGraph) and replayed.
 from __future__ import annotations
 
 import contextlib
+import os
 import ctypes as C
 import time
 from copy import deepcopy
@@ -329,7 +330,9 @@ class PQLVLearner:
         self._restore(snap)
         g = torch.cuda.CUDAGraph()
         g_post = None
-        if not self.dp:
+        # PQL_DP_GRAPH_COLLECTIVE=1 (opt-in, rehearsed with a 1-rank RCCL group only): capture the all-reduce inside ONE graph
+        # instead of splitting the step around an eager collective
+        if not self.dp or os.environ.get("PQL_DP_GRAPH_COLLECTIVE"):
             with torch.cuda.graph(g):
                 self._draw_and_step(ws)
         else:   # two graphs around the RCCL all-reduce (kept eager: no collective is ever captured)
