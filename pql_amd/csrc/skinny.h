@@ -170,7 +170,6 @@ __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
       }
     }
     __syncthreads();
-#if !defined(PQLK_SKDW_NOSTAGE)   // tuning probe only
     if (dy_vec) {   // 16-B loads, all of a thread's quads requested before the first LDS store
       const int qn = p.N >> 2;
       constexpr int QMAX = ROWS * (SKINNY_MAX_N / 4) / 256;
@@ -194,7 +193,6 @@ __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
         dy_lds[r][n] = (m0 + r < m_end) ? dY[(long long)(m0 + r) * p.ldy + n] : 0.f;
       }
     }
-#endif
     __syncthreads();
     // rows rl, rl + RLS, ... of this chunk, loads issued 4 at a time
 #pragma unroll
@@ -243,11 +241,7 @@ __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
   const int ocol = blockIdx.x * (4 * CLS) + 4 * oc;
 #pragma unroll
   for (int half = 0; half < SKINNY_MAX_N / 8; ++half) {
-#if defined(PQLK_SKDW_NOFOLD)   // tuning probe only
-    if (false) {
-#else
     if (8 * half < p.N) {  // block-uniform
-#endif
       __syncthreads();
 #pragma unroll
       for (int nn = 0; nn < 8; ++nn)
