@@ -13,9 +13,15 @@ into the V and P replay rings -> weight hand-off) every 8th step.  So
 Workload = BASELINE.json configs[1]: obs 88, act 16, replay 1M rows pre-filled to capacity and resident in HBM,
 DoubleQ MLP [512,512,256], n-step 3, synthetic transitions.
 
-N > 1: data-parallel weak scaling.  Every rank owns 4096 envs, a 1M-row replay shard and a batch of 8192; the
-only collective on the data path is the RCCL all-reduce of the flat gradient arena before the (replicated)
-optimiser step.  `value` then counts batch-8192 gradient steps summed over ranks (N x steps / time).
+N > 1 (`--layout dp`, default): data-parallel weak scaling.  Every rank owns 4096 envs, a 1M-row replay shard and a
+batch of 8192; the only collective on the data path is the RCCL all-reduce of the flat gradient arena before the
+(replicated) optimiser step.  `value` then counts batch-8192 gradient steps summed over ranks (N x steps / time).
+Started without torchrun (`python bench.py --gpus N`), this script launches the N ranks itself (a torchrun child
+process, before anything here touches a GPU).
+
+`--gpus 2 --layout split2`: BASELINE configs[2], the reference's default placement -- simulator + rollout policy on GPU 0,
+V-learner and P-learner on GPU 1, parameters and transitions shipped over xGMI by copy streams (one process, same metric).
+`--share-gpu` rehearses either layout on ONE card (and says so in `config`; `n_gpus` then stays 1).
 """
 import argparse
 import json
@@ -53,6 +59,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=96, help="schedule steps of the bounded CPU-oracle sample (~15 s)")
     ap.add_argument("--v-only", action="store_true", help="time free-running V-learner steps only")
+    ap.add_argument("--p-only", action="store_true", help="time free-running P-learner steps only (profiling)")
+    ap.add_argument("--layout", default="dp", choices=["dp", "split2"],
+                    help="N>1: dp = one rank per GPU, env/replay shards + RCCL gradient all-reduce; split2 = simulator on GPU 0, "
+                         "both learners on GPU 1 (BASELINE configs[2])")
+    ap.add_argument("--repeat", type=int, default=5, help="timed blocks of --steps steps; `value` is the FIRST block, "
+                                                          "median/min/max over all blocks are reported beside it")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' + --share-gpu rehearses the DP path on one GPU")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
@@ -69,7 +81,7 @@ def flops_per_step(O, A, hidden, out_c, B):
     return 2 * B * (mac_a + 4 * mac_c2), 2 * B * (3 * mac_a + 2 * mac_c2)
 
 
-def build_system(args, rank, world, device, pg):
+def build_system(args, rank, world, device, pg, learner_device=None):
     from pql_amd.algo.pql_actor import PQLActor
     from pql_amd.algo.pql_p_learner import PQLPLearner
     from pql_amd.algo.pql_v_learner import PQLVLearner
@@ -78,7 +90,8 @@ def build_system(args, rank, world, device, pg):
     hidden = [int(x) for x in args.hidden.split(",")]
     ov = [f"num_envs={args.num_envs}", f"task.name={args.task}", f"algo.batch_size={args.batch}",
           f"algo.memory_size={args.replay}", f"algo.nstep={args.nstep}", f"algo.distl={args.distl}",
-          f"algo.v_learner_gpu={device.index}", f"algo.p_learner_gpu={device.index}", "algo.num_gpus=1",
+          f"algo.v_learner_gpu={(learner_device or device).index}", f"algo.p_learner_gpu={(learner_device or device).index}",
+          f"algo.num_gpus={1 if learner_device is None else 2}",
           f"algo.graph={not args.no_graph}", f"algo.streams={not args.no_streams}", f"algo.fused={not args.no_fused}", f"sim_device=cuda:{device.index}",
           f"device=cuda:{device.index}"]
     cfg = load_cfg(ov)
@@ -101,62 +114,71 @@ def build_system(args, rank, world, device, pg):
 
 def prefill(actor, v, p, env, cfg, args, device):
     """Warm-up rollout (train_pql.py:57-68), then fill both replay rings to capacity with synthetic rows so the
-    randint bound is constant and samples come from HBM, not cache."""
+    randint bound is constant and samples come from HBM, not cache.  Returns the newest (critic, policy) snapshots."""
     critic, _, _ = v.start()
     pol, _, _ = p.start()
-    from copy import deepcopy
-    actor.actor = deepcopy(pol)
+    actor.set_actor(pol)
     actor.reset_agent()
     p_data, v_data, _ = actor.explore_env(env, cfg.algo.warm_up, random=True)
-    v.update(pol, v_data, actor.obs_rms.get_states(device), 0)
-    p.update(critic, p_data, actor.obs_rms.get_states(device), 0)
+    critic, _, _ = v.update(pol, v_data, actor.obs_rms.get_states(v.device), 0)
+    pol, _, _ = p.update(critic, p_data, actor.obs_rms.get_states(p.device), 0)
     O, A = env.obs_dim, env.act_dim
     chunk = 65536
-    g = torch.Generator(device=device)
-    g.manual_seed(1234 + device.index)
+    ldev = v.device
+    g = torch.Generator(device=ldev)
+    g.manual_seed(1234 + ldev.index)
     while not v.memory.if_full:
         m = min(chunk, v.memory.capacity)
-        obs = torch.randn((m, O), device=device, generator=g)
-        traj = (obs, torch.rand((m, A), device=device, generator=g) * 2 - 1, torch.randn((m, 1), device=device, generator=g) * 0.01,
-                torch.randn((m, O), device=device, generator=g), (torch.rand((m, 1), device=device, generator=g) < 1 / 300).float())
-        v.update(pol, traj, actor.obs_rms.get_states(device), 0)
-        p.update(critic, obs, actor.obs_rms.get_states(device), 0)
-    torch.cuda.synchronize(device)
+        obs = torch.randn((m, O), device=ldev, generator=g)
+        traj = (obs, torch.rand((m, A), device=ldev, generator=g) * 2 - 1, torch.randn((m, 1), device=ldev, generator=g) * 0.01,
+                torch.randn((m, O), device=ldev, generator=g), (torch.rand((m, 1), device=ldev, generator=g) < 1 / 300).float())
+        critic, _, _ = v.update(pol, traj, actor.obs_rms.get_states(v.device), 0)
+        pol, _, _ = p.update(critic, obs, actor.obs_rms.get_states(p.device), 0)
+    sync_all(device, ldev)
+    return critic, pol
+
+
+def sync_all(*devices):
+    for d in {torch.device(x) for x in devices}:
+        torch.cuda.synchronize(d)
 
 
 class Schedule:
-    """The 1 : 2 : 8 slice schedule (env : P : V)."""
+    """The 1 : 2 : 8 slice schedule (env : P : V).  Hand-offs go through the learners' `update()` exactly as in
+    scripts/train_pql.py: event-fenced, double-buffered, snapshots of the weights (pql_amd/utils/handoff.py)."""
 
-    def __init__(self, actor, v, p, env, cfg, device, v_only=False):
-        self.actor, self.v, self.p, self.env, self.cfg, self.device, self.v_only = actor, v, p, env, cfg, device, v_only
+    def __init__(self, actor, v, p, env, cfg, device, critic, policy, mode="schedule"):
+        self.actor, self.v, self.p, self.env, self.cfg, self.device, self.mode = actor, v, p, env, cfg, device, mode
         self.k = 0
         self.r_p = int(cfg.algo.critic_actor_ratio)
         self.r_env = int(cfg.algo.critic_sample_ratio)
         self.global_steps = 0
         self.pending = None
+        self.critic, self.policy = critic, policy   # newest snapshots handed out by the learners
 
     def step(self):
         """Rollout is software-pipelined one slice ahead, like the reference's asynchronous actor: the transitions
         handed to the learners at slice i were produced (on the rollout queue) while the learners ran slice i-1."""
         k = self.k
         self.k += 1
-        if not self.v_only and k % self.r_env == 0:
-            sim = torch.cuda.current_stream(self.device)          # rollout queue
+        if self.mode == "v_only":
+            self.v.learn()
+            return
+        if self.mode == "p_only":
+            self.p.learn()
+            return
+        if k % self.r_env == 0:
             if self.pending is not None:
-                p_data, v_data, rms = self.pending
-                self.p.critic_stream = self.v.stream
-                self.v.update(self.actor.actor, v_data, rms, 0)  # transitions + policy replica -> V-learner (its queue)
-                self.p.update(self.v.critic, p_data, rms, 0)     # obs + critic replica -> P-learner (its queue)
-            if self.p.stream is not None:
-                sim.wait_stream(self.p.stream)                    # newest policy weights come from the P-learner's queue
-                sim.wait_stream(self.v.stream)                    # and the learners are done reading the last hand-off
-            self.actor.actor.arena.data.copy_(self.p.actor.arena.data)
+                p_data, v_data = self.pending
+                rms = self.actor.obs_rms
+                self.critic, _, _ = self.v.update(self.policy, v_data, rms.get_states(self.v.device), 0)   # transitions + policy -> V
+                self.policy, _, _ = self.p.update(self.critic, p_data, rms.get_states(self.p.device), 0)   # obs + critic -> P
+            self.actor.set_actor(self.policy)                                                               # policy -> rollout
             p_data, v_data, n = self.actor.explore_env(self.env, self.cfg.algo.horizon_len, random=False)
             self.global_steps += n
-            rms = tuple(t.clone() if torch.is_tensor(t) else t for t in self.actor.obs_rms.get_states(self.device))
-            self.pending = (p_data, v_data, rms)
+            self.pending = (p_data, v_data)
         self.v.learn()
-        if not self.v_only and k % self.r_p == self.r_p - 1:
+        if k % self.r_p == self.r_p - 1:
             self.p.learn()
 
 
@@ -240,11 +262,11 @@ def free_running(actor, v, p, env, cfg, device, n=160):
     def rate(fn, reps, per_call=1.0):
         for _ in range(4):
             fn()
-        torch.cuda.synchronize(device)
+        sync_all(device, v.device, p.device)
         t0 = time.perf_counter()
         for _ in range(reps):
             fn()
-        torch.cuda.synchronize(device)
+        sync_all(device, v.device, p.device)
         return per_call * reps / (time.perf_counter() - t0)
 
     out["v_grad_steps_per_s"] = rate(v.learn, n)
@@ -316,16 +338,47 @@ def cpu_baseline(args, O, A, hidden):
                       f"batch {B}, hidden {list(hidden)}, replay {cap} rows, torch {torch.__version__} CPU, {dt:.1f} s"}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as a torchrun CHILD process and leave with its exit
+    code.  Runs before this process has made any HIP call (device_count() does not initialise the GPU on this image), so
+    no process that has touched a GPU ever execs or forks."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if not args.share_gpu and have < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible (use --share-gpu to rehearse on one card)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    raise SystemExit(subprocess.run(cmd).returncode)
+
+
 def main():
     args = parse()
+    split = args.layout == "split2"
+    if split and args.gpus != 2:
+        raise SystemExit("--layout split2 is the two-GPU placement: use --gpus 2")
+    if args.gpus > 1 and not split and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != (1 if split else args.gpus):
+        raise SystemExit(f"--gpus {args.gpus} --layout {args.layout} but WORLD_SIZE={world}")
+    have = torch.cuda.device_count()
+    if not args.share_gpu and have < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus}: only {have} GPU(s) visible (use --share-gpu to rehearse on one card)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
-    device = torch.device("cuda:0" if args.share_gpu else f"cuda:{local}")
+    device = torch.device("cuda:0" if (args.share_gpu or split) else f"cuda:{local}")
+    learner_device = None
+    if split:
+        learner_device = torch.device("cuda:0" if args.share_gpu else "cuda:1")
+        if args.share_gpu:   # one card: still go through the copy streams and landing blocks of the two-GPU path
+            from pql_amd.utils import handoff
+            handoff.FORCE_SHIP = True
     torch.cuda.set_device(device)
     pg = None
     if world > 1 or os.environ.get("PQL_FORCE_DP"):   # PQL_FORCE_DP=1: rehearse the RCCL path with a 1-rank group
@@ -336,6 +389,8 @@ def main():
         else:
             torch.distributed.init_process_group(args.backend)
         pg = torch.distributed.group.WORLD
+        if torch.distributed.get_world_size(pg) != world:
+            raise SystemExit(f"process group has {torch.distributed.get_world_size(pg)} ranks, expected {world}")
     torch.manual_seed(42 + rank)
 
     def note(msg):
@@ -343,53 +398,77 @@ def main():
             print(f"[bench +{time.perf_counter() - t_start:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
     t_start = time.perf_counter()
-    cfg, env, actor, v, p = build_system(args, rank, world, device, pg)
+    cfg, env, actor, v, p = build_system(args, rank, world, device, pg, learner_device)
     note("system built")
-    prefill(actor, v, p, env, cfg, args, device)
+    critic, policy = prefill(actor, v, p, env, cfg, args, device)
     note(f"replay pre-filled: {v.memory.cur_capacity} rows x {v.memory.ring.rec_ld * 4} B")
-    sched = Schedule(actor, v, p, env, cfg, device, v_only=args.v_only)
+    mode = "v_only" if args.v_only else "p_only" if args.p_only else "schedule"
+    sched = Schedule(actor, v, p, env, cfg, device, critic, policy, mode=mode)
+    devices = (device, v.device, p.device)
 
     def barrier():
         if pg is not None:
             torch.distributed.barrier(group=pg)
 
+    def timed_block():
+        """EXACTLY --steps steps between barrier + device synchronisation on both sides; max over ranks."""
+        barrier()
+        sync_all(*devices)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sched.step()
+        sync_all(*devices)
+        barrier()
+        dt = time.perf_counter() - t0
+        if pg is not None:
+            tt = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX, group=pg)
+            dt = float(tt.item())
+        return dt
+
     for _ in range(args.warmup):
         sched.step()
-    torch.cuda.synchronize(device)
+    sync_all(*devices)
     note("warm-up done")
-    barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sched.step()
-    torch.cuda.synchronize(device)
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed_block()
     note(f"timed {args.steps} steps in {dt:.3f} s")
-    if pg is not None:
-        tt = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX, group=pg)
-        dt = float(tt.item())
+    blocks = [dt] + [timed_block() for _ in range(max(args.repeat, 1) - 1)]
 
     hidden = [int(x) for x in args.hidden.split(",")]
     O, A = env.obs_dim, env.act_dim
     out_c = 51 if args.distl else 1
     f_v, f_p = flops_per_step(O, A, hidden, out_c, args.batch)
     value = world * args.steps / dt
+    rates = sorted(world * args.steps / t for t in blocks)
+    n_gpus = 1 if args.share_gpu else args.gpus
+    if split:
+        par = "split2 (simulator + rollout policy on GPU 0, V- and P-learner on GPU 1, copy-stream hand-offs over xGMI)"
+    elif world > 1:
+        par = f"dp{world}"
+    else:
+        par = "single"
+    backend = torch.distributed.get_backend(pg) if pg is not None else None
+    unit = {"schedule": "V-learner grad-steps/s", "v_only": "V-learner grad-steps/s", "p_only": "P-learner grad-steps/s"}[mode]
     line = {
         "metric": "learner grad-steps/sec + env-steps/sec, 4096 envs batch 8192 (value = V-learner grad-steps/s at the 1:2:8 "
                   "env:P:V schedule; batch-8192 steps summed over ranks)",
-        "value": value, "unit": "V-learner grad-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": value, "unit": unit, "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"PQL {world}xMI355X{' per rank (data parallel, RCCL grad all-reduce)' if world > 1 else ''}: "
+        "config": {"workload": f"PQL {args.gpus}xMI355X"
+                               f"{' per rank (data parallel, ' + ('RCCL' if backend == 'nccl' else str(backend)) + ' grad all-reduce)' if world > 1 else ''}"
+                               f"{' functional split' if split else ''}: "
                                f"{args.num_envs} synthetic envs ({args.task}-shape obs={O} act={A}), replay "
                                f"{args.replay} rows resident in HBM, batch {args.batch}, n-step {args.nstep}, "
                                f"{'DistributionalDoubleQ(51)' if args.distl else 'DoubleQ'} MLP {hidden}",
-                   "schedule": "v_only" if args.v_only else "1 env-iteration : 4 P-steps : 8 V-steps",
-                   "graph": not args.no_graph, "streams": not args.no_streams, "fused_forward": not args.no_fused, "parallelism": f"dp{world}" if world > 1 else "single"},
-        "p_grad_steps_per_s": 0.0 if args.v_only else value / int(cfg.algo.critic_actor_ratio),
-        "env_steps_per_s": 0.0 if args.v_only else value / int(cfg.algo.critic_sample_ratio) * args.num_envs,
+                   "schedule": {"schedule": "1 env-iteration : 4 P-steps : 8 V-steps", "v_only": "v_only", "p_only": "p_only"}[mode],
+                   "graph": not args.no_graph, "streams": not args.no_streams, "fused_forward": not args.no_fused,
+                   "parallelism": par, "layout": args.layout if args.gpus > 1 else "single", "ranks": world,
+                   "backend": backend, "share_gpu": bool(args.share_gpu)},
+        "repeats": {"blocks": len(blocks), "steps_per_block": args.steps, "median": rates[len(rates) // 2], "min": rates[0],
+                    "max": rates[-1], "note": "`value` is the first block; same unit"},
+        "p_grad_steps_per_s": value / int(cfg.algo.critic_actor_ratio) if mode == "schedule" else 0.0,
+        "env_steps_per_s": value / int(cfg.algo.critic_sample_ratio) * args.num_envs if mode == "schedule" else 0.0,
         "gflop_per_v_step": f_v / 1e9, "gflop_per_p_step": f_p / 1e9,
     }
     if rank == 0:
@@ -416,7 +495,7 @@ def main():
                                    "traffic": traffic.get("gather_per_launch_bytes"), "algorithmic_bytes": alg_bytes,
                                    "us_per_launch": gms * 1e3, "record_bytes": rec_ld * 4}
         note("roofline sections measured")
-        if world == 1 and not args.v_only:
+        if world == 1 and mode == "schedule":
             line["free_running"] = free_running(actor, v, p, env, cfg, device)
             note("free-running rates measured")
         if not args.no_cpu_baseline and world == 1:

@@ -598,3 +598,44 @@ class CrossQRef:
         aloss = -torch.min(q1, q2).mean()
         self.aopt.apply(list(torch.autograd.grad(aloss, self.actor)), hp.max_grad_norm)
         return float(closs.detach()), float(aloss.detach())
+
+
+# --------------------------------------------------------------------------------------------------------------
+# a25: the speed-ratio control law of the main loop (scripts/train_pql.py:72-88 state, :127-166 law + bookkeeping).
+# Plain-Python restatement used to check pql_amd.utils.ratio_control.RatioController; "parity unpinned" beyond that:
+# the reference has no fixture for it and its inputs are wall-clock times, so the check is law-vs-law on a
+# scripted sequence of (time, critic count, actor count) observations.
+def ratio_control_ref(observations, critic_sample_ratio=8, critic_actor_ratio=2, first=(0.0, 0, 0)):
+    """observations: [(time at the end of rollout iteration i, critic_update_times, actor_update_times)], i = 1..n;
+    `first` = (time, critic, actor) of the entry made before the loop (:79-85).  Returns the (sim_wait_time,
+    critic_wait_time, actor_wait_time) in force after each iteration."""
+    from collections import deque
+    window = deque(maxlen=100)                                                   # :77-78
+    waits = dict(sim=0, critic=0, actor=0)                                       # :73-76
+    window.append(dict(time=first[0], sim=0, critic=first[1], actor=first[2], **{k + "_w": v for k, v in waits.items()}))
+    out = []
+    for sim_count, (now, n_cri, n_act) in enumerate(observations, start=1):      # :97-99
+        if len(window) >= 10 and n_act != 0 and n_cri != 0:                      # :127
+            head = window[0]
+            dt = now - head["time"]                                              # :128
+            try:
+                sim_u, cri_u, act_u = dt / (sim_count - head["sim"]), dt / (n_cri - head["critic"]), dt / (n_act - head["actor"])
+            except ZeroDivisionError:                                            # the reference would raise here; the build skips
+                sim_u = None
+            if sim_u is not None:
+                w = sim_u / critic_sample_ratio - cri_u                          # :133
+                if w > 0:
+                    if waits["sim"] == 0:
+                        waits["critic"] = head["critic_w"] + w                  # :136
+                    else:
+                        waits["sim"] = max(0, head["sim_w"] - w)                # :138
+                else:
+                    if waits["critic"] == 0:
+                        waits["sim"] = head["sim_w"] - w                        # :141
+                    else:
+                        waits["critic"] = max(0, head["critic_w"] + w)          # :143
+                w = cri_u * critic_actor_ratio - act_u                           # :145
+                waits["actor"] = head["actor_w"] + w if w > 0 else max(0, head["actor_w"] + w)   # :146-149
+        window.append(dict(time=now, sim=sim_count, critic=n_cri, actor=n_act, **{k + "_w": v for k, v in waits.items()}))   # :151-157
+        out.append((waits["sim"], waits["critic"], waits["actor"]))
+    return out

@@ -12,6 +12,7 @@ from __future__ import annotations
 import torch
 
 from pql_amd.replay.nstep_replay import NStepReplay
+from pql_amd.utils import handoff as H
 from pql_amd.utils.common import handle_timeout
 from pql_amd.utils.noise import add_mixed_normal_noise, add_normal_noise
 from pql_amd.utils.schedule_util import ExponentialSchedule, LinearSchedule
@@ -28,9 +29,14 @@ class DeviceTracker:
         self.ptr = torch.zeros((), dtype=torch.int64, device=device)
 
     def update(self, values, mask):
-        pos = (self.ptr + torch.cumsum(mask.to(torch.int64), 0) - 1) % self.max_len
-        self.ring.scatter_(0, torch.where(mask, pos, torch.full_like(pos, self.max_len)), values)
-        self.ptr = (self.ptr + mask.sum()) % self.max_len
+        """deque.extend(values[mask]) of common.Tracker: when more than max_len episodes finish in one step only the LAST
+        max_len of them (in env order) stay, so every kept value has a slot of its own and the scatter is deterministic."""
+        rank = torch.cumsum(mask.to(torch.int64), 0)
+        total = rank[-1]
+        keep = mask & (rank > total - self.max_len)
+        pos = (self.ptr + rank - 1) % self.max_len
+        self.ring.scatter_(0, torch.where(keep, pos, torch.full_like(pos, self.max_len)), values)
+        self.ptr = (self.ptr + total) % self.max_len
 
     def mean(self):
         return float(self.ring[: self.max_len].mean())
@@ -42,6 +48,8 @@ class PQLActor:
         self.obs_dim = env.observation_space.shape
         self.action_dim = env.action_space.shape[0]
         self.sim_device = torch.device(f"{cfg.sim_device}")
+        if self.sim_device.type == "cuda" and self.sim_device.index is None:
+            self.sim_device = torch.device("cuda", torch.cuda.current_device())
         self.v_learner_device = torch.device(f"cuda:{cfg.algo.v_learner_gpu}")
         self.p_learner_device = torch.device(f"cuda:{cfg.algo.p_learner_gpu}")
         self.env_offset, self.total_envs = int(env_offset), total_envs   # position on the GLOBAL env axis (data parallel)
@@ -58,6 +66,11 @@ class PQLActor:
         self.n_step_buffer = NStepReplay(self.obs_dim, self.action_dim, n, algo.nstep, device=dev)
         self.noise_scheduler = self._make_scheduler(algo.noise)
         self._slabs = {}   # (N, T, .) trajectory slabs, allocated once per horizon length and reused
+        # n-step output blocks handed to the learners: OUT_BLOCKS per block size, each with a lease so that the rollout
+        # stream re-uses one only after the learners' streams have inserted it (pql_amd.utils.handoff)
+        self._out_blocks, self._out_next = {}, {}
+
+    OUT_BLOCKS = 3
 
     @staticmethod
     def _make_scheduler(noise):
@@ -92,6 +105,42 @@ class PQLActor:
         if noise.type == "fixed":
             return add_normal_noise(act, std=self.get_noise_std(), out_bounds=[-1., 1.])
         raise NotImplementedError(noise.type)
+
+    @torch.no_grad()
+    def set_actor(self, actor):
+        """Adopt new policy weights into the rollout replica (train_pql.py:52,109 `pql_actor.actor = deepcopy(actor).to(
+        sim_device)`): a fenced arena-to-arena copy; from another GPU it goes through the copy streams."""
+        if self.actor is None or self.actor.layout.dims != actor.layout.dims:
+            from copy import deepcopy
+            self.actor = deepcopy(actor).to(self.sim_device)
+            return
+        if actor is self.actor:
+            return
+        st = torch.cuda.current_stream(self.sim_device)
+        with H.LOCK:
+            if H.crosses(actor.arena.device, self.sim_device):
+                blk = H.shipper(actor.arena.device, self.sim_device, "params").ship((actor.arena.data,), H.lease_of(actor))
+                lease = H.acquire(blk, st)
+                self.actor.arena.data.copy_(blk[0], non_blocking=True)
+            else:
+                lease = H.acquire(actor, st)
+                self.actor.arena.data.copy_(actor.arena.data, non_blocking=True)
+            H.release(lease, st)
+
+    def _out_block(self, M):
+        """Next n-step output block of M rows (round robin), reclaimed from its previous readers."""
+        blocks = self._out_blocks.setdefault(M, [])
+        k = self._out_next.get(M, 0)
+        self._out_next[M] = (k + 1) % self.OUT_BLOCKS
+        if k >= len(blocks):
+            dev = self.sim_device
+            O = self.obs_dim[0] if not isinstance(self.obs_dim, int) else self.obs_dim
+            mk = lambda c: torch.empty((M, c), dtype=torch.float32, device=dev)  # noqa: E731
+            blocks.append(H.Block((mk(O), mk(self.action_dim), mk(1), mk(O), mk(1)), H.Lease()))
+        blk = blocks[k]
+        with H.LOCK:
+            H.reclaim(H.lease_of(blk), torch.cuda.current_stream(self.sim_device))
+        return blk
 
     # ---- rollout --------------------------------------------------------------------------------
     def _trajectory_slabs(self, T):
@@ -131,10 +180,22 @@ class PQLActor:
             obs = next_obs
         self.obs = obs
         rew = sl["rew"] * algo.reward_scale
-        out = self.n_step_buffer.add_to_buffer(sl["obs"], sl["act"], rew, sl["nobs"], sl["done"])
-        O = out[0].shape[-1]
-        p_data = out[0].reshape(-1, O).to(self.p_learner_device, non_blocking=True)
-        v_data = tuple(x.to(self.v_learner_device, non_blocking=True) for x in out)
+        blk = self._out_block(self.n_step_buffer.rows_out(timesteps))
+        self.n_step_buffer.add_to_buffer(sl["obs"], sl["act"], rew, sl["nobs"], sl["done"], out=tuple(blk))
+        sim = torch.cuda.current_stream(self.sim_device)
+        with H.LOCK:
+            H.lease_of(blk).ready = H._event(sim)
+        # hand-off (pql_actor.py:121-126: `.to(learner_device)`): same GPU -> the block itself; another GPU -> copy
+        # streams + landing blocks on that GPU.  Either way the learner's stream, not the host, waits for the data.
+        v_data = blk if not H.crosses(self.sim_device, self.v_learner_device) else \
+            H.shipper(self.sim_device, self.v_learner_device, "transitions").ship(tuple(blk), H.lease_of(blk))
+        if self.p_learner_device == self.v_learner_device:
+            p_data = H.tag(v_data[0].view(v_data[0].shape), H.lease_of(v_data))
+        elif not H.crosses(self.sim_device, self.p_learner_device):
+            p_data = H.tag(blk[0].view(blk[0].shape), H.lease_of(blk))
+        else:
+            p_data = H.shipper(self.sim_device, self.p_learner_device, "obs").ship((blk[0],), H.lease_of(blk))
+            p_data = H.tag(p_data[0], H.lease_of(p_data))
         return p_data, v_data, timesteps * n
 
     def update_tracker(self, reward, done, info):

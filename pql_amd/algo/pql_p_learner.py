@@ -12,18 +12,19 @@ learn()  (reference :47-64)  ->  one launch sequence
 from __future__ import annotations
 
 import contextlib
-import os
 import ctypes as C
-import time
+import threading
 from copy import deepcopy
 
 import torch
 
 from pql_amd import _lib as L
-from pql_amd.algo.pql_v_learner import LOSS_RING, LaggedLoss, allreduce_sum, _AdamState, _cfg_get, apply_optimizer, resident_norm
+from pql_amd.algo.pql_v_learner import (LOSS_RING, LaggedLoss, _AdamState, _cfg_get, adopt_arena, allreduce_sum, apply_optimizer,
+                                        graph_collective_enabled, pump, resident_norm)
 from pql_amd.models import model_name_to_path
 from pql_amd.models.mlp import PackedWeights, default_splits, mlp_forward_raw, output_view
 from pql_amd.replay.simple_replay import RecordRing, _obs_width, ring_plan
+from pql_amd.utils import handoff as H
 from pql_amd.utils.common import Tracker, load_class_from_path
 
 
@@ -68,6 +69,10 @@ class PQLPLearner:
         self.sleep_time = 0.01
         self.use_graph = bool(_cfg_get(algo, "graph", False))
         self.stream = torch.cuda.Stream(self.device) if bool(_cfg_get(algo, "streams", False)) else None
+        # start()/update() hand out double-buffered snapshots of the actor (a pickled copy in the reference)
+        self._pub = H.ArenaPublisher(self.actor)
+        self._lock = threading.RLock()   # learn() / update() are FIFO like calls on a Ray actor
+        self.gen = None                  # private RNG (use_private_rng)
         self._ws = None
         self._graph = None
         self._graph_post = None
@@ -79,10 +84,32 @@ class PQLPLearner:
         return self.ring.records[:, : self.ring.O]
 
     def start(self):
-        return self.actor, self.update_count, self.loss_tracker.mean()
+        with self._lock, torch.cuda.device(self.device), self._on_stream():
+            return self._published(), self.update_count, self.loss_tracker.mean()
 
     def _on_stream(self):
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def _published(self):
+        """The actor as handed to other components: a snapshot taken on this learner's queue."""
+        return self._pub.publish()
+
+    def use_private_rng(self, seed):
+        """Own device generator for a free-running learner thread (see PQLVLearner.use_private_rng)."""
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed))
+        self._graph = None
+
+    def ready_to_learn(self):
+        return self.critic is not None
+
+    def fence(self):
+        ev = torch.cuda.Event()
+        ev.record(self.stream if self.stream is not None else torch.cuda.current_stream(self.device))
+        return ev
+
+    def synchronize(self):
+        self.fence().synchronize()
 
     def _workspace(self, B):
         if self._ws is not None and self._ws["B"] == B:
@@ -156,7 +183,7 @@ class PQLPLearner:
                         1.0 / self.world, self.device, layout=self.actor.layout, packed=self.pk_actor)
 
     def _draw_and_step(self, ws, upto_backward=False):
-        ws["idx"].copy_(torch.randint(self.cur_capacity, size=(ws["B"],), device=self.device))  # the only draw (:49)
+        ws["idx"].copy_(torch.randint(self.cur_capacity, size=(ws["B"],), device=self.device, generator=self.gen))  # the only draw (:49)
         self._step_kernels(ws, ws["idx"], upto_backward)
 
     @torch.no_grad()
@@ -164,10 +191,15 @@ class PQLPLearner:
         if self.critic is None:
             return self.sleep_time
         B = int(self.cfg.algo.batch_size)
-        with torch.cuda.device(self.device), self._on_stream():
+        home = torch.cuda.current_stream(self.device)
+        with self._lock, torch.cuda.device(self.device), self._on_stream():
             ws = self._workspace(B)
-            if indices is not None:
-                self._step_kernels(ws, indices.to(self.device, torch.int64).contiguous())
+            if indices is not None:   # injected draw: arrives on the caller's stream (or from the host)
+                st = torch.cuda.current_stream(self.device)
+                lease = H.acquire(indices, st, home) if indices.is_cuda else None
+                ws["idx"].copy_(indices.reshape(-1), non_blocking=indices.is_cuda)
+                H.release(lease, st)
+                self._step_kernels(ws, ws["idx"])
             elif self.use_graph:
                 key = (B, self.cur_capacity, id(self.critic), self.normalize_tuple is None)
                 if self._graph is None or self._graph_key != key:
@@ -184,9 +216,24 @@ class PQLPLearner:
     def _state(self):
         return (self.actor.arena.data, self.opt.m, self.opt.v, self.opt.step, self.loss_ring)
 
+    def _new_graph(self):
+        g = torch.cuda.CUDAGraph()
+        if self.gen is not None:
+            g.register_generator_state(self.gen)
+        return g
+
+    def _rng_state(self):
+        return self.gen.get_state() if self.gen is not None else torch.cuda.get_rng_state(self.device)
+
+    def _set_rng_state(self, state):
+        if self.gen is not None:
+            self.gen.set_state(state)
+        else:
+            torch.cuda.set_rng_state(state, self.device)
+
     def _capture(self, ws, key):
         snap = [t.clone() for t in self._state()]
-        rng = torch.cuda.get_rng_state(self.device)
+        rng = self._rng_state()
         s = torch.cuda.Stream(self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
@@ -195,21 +242,20 @@ class PQLPLearner:
         for dst, src in zip(self._state(), snap):
             dst.copy_(src)
         self.repack()
-        torch.cuda.set_rng_state(rng, self.device)
-        g = torch.cuda.CUDAGraph()
-        g_post = None
-        # PQL_DP_GRAPH_COLLECTIVE=1 (opt-in, rehearsed with a 1-rank RCCL group only): capture the all-reduce inside ONE graph
-        # instead of splitting the step around an eager collective
-        if not self.dp or os.environ.get("PQL_DP_GRAPH_COLLECTIVE"):
-            with torch.cuda.graph(g):
+        self._set_rng_state(rng)
+        g, g_post = self._new_graph(), None
+        # PQL_DP_GRAPH_COLLECTIVE=1 (opt-in, RCCL only, rehearsed with a 1-rank group only): capture the all-reduce inside
+        # ONE graph instead of splitting the step around an eager collective
+        if not self.dp or graph_collective_enabled(self.pg):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._draw_and_step(ws)
         else:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._draw_and_step(ws, upto_backward=True)
-            g_post = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_post):
+            g_post = self._new_graph()
+            with torch.cuda.graph(g_post, capture_error_mode="thread_local"):
                 self._step_post(ws)
-        torch.cuda.set_rng_state(rng, self.device)
+        self._set_rng_state(rng)
         self._graph, self._graph_post, self._graph_key = g, g_post, key
 
     def loss_mean(self):
@@ -222,46 +268,46 @@ class PQLPLearner:
             self.loss_tracker.update(vals[t % LOSS_RING])
         return m
 
-    def set_critic(self, critic):
-        """Adopt new critic weights into a resident replica (flat arena copy; peer copy over xGMI when the
-        V-learner lives on another GPU) -- the reference pickles the whole module through Ray instead."""
+    def set_critic(self, critic, home=None):
+        """Adopt new critic weights into a resident replica: fenced flat-arena copy on this learner's stream (through
+        the copy streams / xGMI when the V-learner lives on another GPU) -- the reference pickles the whole module."""
         if self.critic is None or self.critic.layout.dims != critic.layout.dims:
-            self.critic = deepcopy(critic).to(self.device)
+            st = torch.cuda.current_stream(self.device)
+            with H.LOCK:
+                lease = H.acquire(critic, st, home)
+                self.critic = deepcopy(critic).to(self.device)
+                H.release(lease, st)
+            self.critic.requires_grad_(False)
             if hasattr(self.critic, "z_atoms"):
                 self.critic.z_atoms = self.critic.z_atoms.to(self.device)
                 self.critic.device = self.device
             self.pk_critic = PackedWeights(self.critic.layout, self.device) if self._fused else None
         elif critic is not self.critic:
-            self.critic.arena.data.copy_(critic.arena.data, non_blocking=True)
+            adopt_arena(self.critic, critic, self.device, home)
         if self.pk_critic is not None:
             self.pk_critic.refresh(self.critic.arena.data)
 
     @torch.no_grad()
     def update(self, critic, obs, normalize_tuple, sleep_time):
-        with torch.cuda.device(self.device), self._on_stream():
-            if self.stream is not None:
-                self.stream.wait_stream(torch.cuda.default_stream(self.device) if getattr(self, "producer_stream", None) is None
-                                        else self.producer_stream)
-                critic_stream = getattr(self, "critic_stream", None)
-                if critic_stream is not None:
-                    self.stream.wait_stream(critic_stream)   # newest critic weights are produced on the V-learner's stream
-                if obs.is_cuda:
-                    obs.record_stream(self.stream)
-            self.set_critic(critic)
+        """pql_p_learner.py:66-85, enqueued on this learner's stream behind event fences (see PQLVLearner.update)."""
+        home = torch.cuda.current_stream(self.device)
+        with self._lock, torch.cuda.device(self.device), self._on_stream():
+            st = torch.cuda.current_stream(self.device)
+            self.set_critic(critic, home)
             self.sleep_time = sleep_time
-            self.normalize_tuple = resident_norm(self, normalize_tuple)
-            obs = obs.reshape(-1, self.ring.O).to(self.device, torch.float32).contiguous()
-            self.add_capacity = obs.shape[0]
-            segs, self.next_p, self.if_full, self.cur_capacity = ring_plan(self.next_p, self.if_full, self.memory_size,
-                                                                           obs.shape[0])
-            self.ring.insert_segments(segs, obs)
+            self.normalize_tuple = resident_norm(self, normalize_tuple, home)
+            with H.LOCK:
+                lease = H.acquire(obs, st, home)
+                obs = obs.reshape(-1, self.ring.O).to(self.device, torch.float32).contiguous()
+                self.add_capacity = obs.shape[0]
+                segs, self.next_p, self.if_full, self.cur_capacity = ring_plan(self.next_p, self.if_full, self.memory_size,
+                                                                               obs.shape[0])
+                self.ring.insert_segments(segs, obs)
+                H.release(lease, st)
             loss = self._lagged.poll(self.update_count)
-        return self.actor, loss, self.update_count
+            return self._published(), loss, self.update_count
 
 
-def asyn_p_learner(learner, cfg, stop_event=None):
+def asyn_p_learner(learner, cfg, stop_event=None, max_in_flight=2):
     """Free-running pump (reference: a Ray task, :99-104).  Run it in a thread."""
-    while stop_event is None or not stop_event.is_set():
-        sleep_time = learner.learn()
-        if sleep_time:
-            time.sleep(sleep_time)
+    pump(learner, stop_event, max_in_flight)

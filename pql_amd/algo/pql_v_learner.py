@@ -17,7 +17,9 @@ from __future__ import annotations
 import contextlib
 import os
 import ctypes as C
+import threading
 import time
+from collections import deque
 from copy import deepcopy
 
 import torch
@@ -26,6 +28,7 @@ from pql_amd import _lib as L
 from pql_amd.models import model_name_to_path
 from pql_amd.models.mlp import PackedWeights, default_splits, mlp_forward_raw, output_view
 from pql_amd.replay.simple_replay import ReplayBuffer
+from pql_amd.utils import handoff as H
 from pql_amd.utils.common import Tracker, load_class_from_path
 
 LOSS_RING = 5  # Tracker(5) of the reference (:54)
@@ -111,9 +114,21 @@ class LaggedLoss:
         return self.value
 
 
-def resident_norm(owner, normalize_tuple):
+def graph_collective_enabled(pg):
+    """PQL_DP_GRAPH_COLLECTIVE=1 captures the gradient all-reduce inside the learner's hipGraph.  Only RCCL can be
+    captured (the gloo rehearsal path stages through the host); rehearsed with a 1-rank group only -- unverified for
+    world > 1, scaling was not measurable on this pool."""
+    if os.environ.get("PQL_DP_GRAPH_COLLECTIVE", "0") != "1":
+        return False
+    if torch.distributed.get_backend(pg) != "nccl":
+        raise L.PqlkError("PQL_DP_GRAPH_COLLECTIVE=1 needs the RCCL ('nccl') backend: a gloo all-reduce cannot be graph-captured")
+    return True
+
+
+def resident_norm(owner, normalize_tuple, home=None):
     """Copy (mean, var, eps) into buffers that live as long as the learner, so kernels (and captured
-    graphs) always read the same addresses; the producer may hand over fresh tensors every iteration."""
+    graphs) always read the same addresses; the producer may hand over fresh tensors every iteration.
+    Runs on the learner's stream (current), fenced against the stream the tensors were produced on."""
     if normalize_tuple is None:
         return None
     mean, var, eps = normalize_tuple
@@ -122,9 +137,49 @@ def resident_norm(owner, normalize_tuple):
         cur = (torch.empty(mean.numel(), dtype=torch.float32, device=owner.device),
                torch.empty(var.numel(), dtype=torch.float32, device=owner.device))
         owner._norm_buf = cur
-    cur[0].copy_(mean.reshape(-1), non_blocking=True)
-    cur[1].copy_(var.reshape(-1), non_blocking=True)
+    st = torch.cuda.current_stream(owner.device)
+    for dst, src in zip(cur, (mean, var)):
+        with H.LOCK:
+            lease = H.acquire(src, st, home)
+            dst.copy_(src.reshape(-1), non_blocking=True)
+            H.release(lease, st)
     return cur[0], cur[1], float(eps)
+
+
+def adopt_arena(dst_module, src_module, device, home=None, pipe="params"):
+    """Fenced copy of `src_module`'s flat arena into `dst_module`'s on the CURRENT stream of `device`: waits for the
+    producer (a published snapshot's event, or the caller's stream for a plain module) and releases the source
+    afterwards.  From another GPU the bytes first land in a double-buffered block through the copy streams (peer copy
+    over xGMI), so the learner's compute stream only ever does the local arena copy."""
+    st = torch.cuda.current_stream(device)
+    with H.LOCK:
+        if H.crosses(src_module.arena.device, device):
+            blk = H.shipper(src_module.arena.device, device, pipe).ship((src_module.arena.data,), H.lease_of(src_module))
+            lease = H.acquire(blk, st)
+            dst_module.arena.data.copy_(blk[0], non_blocking=True)
+        else:
+            lease = H.acquire(src_module, st, home)
+            dst_module.arena.data.copy_(src_module.arena.data, non_blocking=True)
+        H.release(lease, st)
+
+
+def pump(learner, stop_event=None, max_in_flight=2):
+    """Free-running learner loop shared by asyn_v_learner / asyn_p_learner.  The host enqueues a step in ~15 us and the
+    GPU takes ~0.7 ms to run it, so without back-pressure the queue would run thousands of steps ahead of the device and
+    every `update()` would land behind them: at most `max_in_flight` steps are kept enqueued (event wait, GIL released)."""
+    pending = deque()
+    while stop_event is None or not stop_event.is_set():
+        if not learner.ready_to_learn():
+            time.sleep(0.0005)
+            continue
+        sleep_time = learner.learn()
+        pending.append(learner.fence())
+        while len(pending) > max_in_flight:
+            pending.popleft().synchronize()
+        if sleep_time:
+            time.sleep(sleep_time)
+    while pending:
+        pending.popleft().synchronize()
 
 
 class PQLVLearner:
@@ -174,6 +229,12 @@ class PQLVLearner:
         # own HIP stream: the MI355X form of the reference's separate learner process (Ray actor).  V-learner,
         # P-learner and rollout queues then overlap on the GPU; hand-offs are event-fenced in update().
         self.stream = torch.cuda.Stream(self.device) if bool(_cfg_get(algo, "streams", False)) else None
+        # what start()/update() hand out: double-buffered snapshots of the critic (the reference returns a pickled copy
+        # through Ray, pql_v_learner.py:59-60,122), so a consumer never reads an arena AdamW is writing and the weights a
+        # caller holds are those of the hand-off, not of whenever it gets round to using them
+        self._pub = H.ArenaPublisher(self.critic)
+        self._lock = threading.RLock()   # learn() / update() are FIFO like calls on a Ray actor
+        self.gen = None                  # private RNG (use_private_rng): one generator per free-running learner thread
         self._ws = None
         self._graph = None
         self._graph_post = None
@@ -181,10 +242,35 @@ class PQLVLearner:
 
     # ------------------------------------------------------------------------------------------
     def start(self):
-        return self.critic, self.update_count, self.loss_tracker.mean()
+        with self._lock, torch.cuda.device(self.device), self._on_stream():
+            return self._published(), self.update_count, self.loss_tracker.mean()
 
     def _on_stream(self):
         return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def _published(self):
+        """The critic as handed to other components: a snapshot taken on this learner's queue."""
+        return self._pub.publish()
+
+    def use_private_rng(self, seed):
+        """Give this learner its own device generator (the reference's learners are separate processes with their own
+        default generators).  Needed when learners free-run in threads: two threads must not interleave draws -- or a
+        graph capture -- on the shared default generator."""
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed))
+        self._graph = None
+
+    def ready_to_learn(self):
+        return self.actor is not None
+
+    def fence(self):
+        """Event behind everything enqueued on this learner's queue so far."""
+        ev = torch.cuda.Event()
+        ev.record(self.stream if self.stream is not None else torch.cuda.current_stream(self.device))
+        return ev
+
+    def synchronize(self):
+        self.fence().synchronize()
 
     def _workspace(self, B):
         if self._ws is not None and self._ws["B"] == B:
@@ -285,8 +371,8 @@ class PQLVLearner:
         B = ws["B"]
         # RNG consumption order of the reference: one randint(cur_capacity,(B,)) then one
         # N(0,1) draw of shape (B, A) on the learner's device generator.
-        ws["idx"].copy_(torch.randint(self.memory.cur_capacity, size=(B,), device=self.device))
-        ws["draw"].normal_()
+        ws["idx"].copy_(torch.randint(self.memory.cur_capacity, size=(B,), device=self.device, generator=self.gen))
+        ws["draw"].normal_(generator=self.gen)
         self._step_kernels(ws, ws["idx"], ws["draw"], upto_backward)
 
     @torch.no_grad()
@@ -296,14 +382,19 @@ class PQLVLearner:
         if self.actor is None:
             return self.sleep_time
         B = int(self.cfg.algo.batch_size)
-        with torch.cuda.device(self.device), self._on_stream():
+        home = torch.cuda.current_stream(self.device)
+        with self._lock, torch.cuda.device(self.device), self._on_stream():
             ws = self._workspace(B)
             if indices is not None or noise is not None:
-                idx = (indices.to(self.device, torch.int64).contiguous() if indices is not None
-                       else torch.randint(self.memory.cur_capacity, size=(B,), device=self.device))
-                draw = (noise.to(self.device, torch.float32).contiguous() if noise is not None
-                        else torch.empty((B, self.action_dim), device=self.device).normal_())
-                self._step_kernels(ws, idx, draw)
+                if indices is not None:   # injected draws arrive on the caller's stream (or from the host)
+                    self._inject(ws["idx"], indices, home)
+                else:
+                    ws["idx"].copy_(torch.randint(self.memory.cur_capacity, size=(B,), device=self.device, generator=self.gen))
+                if noise is not None:
+                    self._inject(ws["draw"], noise, home)
+                else:
+                    ws["draw"].normal_(generator=self.gen)
+                self._step_kernels(ws, ws["idx"], ws["draw"])
             elif self.use_graph:
                 key = (B, self.memory.cur_capacity, id(self.actor), self.normalize_tuple is None)
                 if self._graph is None or self._graph_key != key:
@@ -317,6 +408,12 @@ class PQLVLearner:
         self.update_count += 1
         return self.sleep_time
 
+    def _inject(self, dst, src, home):
+        st = torch.cuda.current_stream(self.device)
+        lease = H.acquire(src, st, home) if src.is_cuda else None
+        dst.copy_(src.reshape(dst.shape), non_blocking=src.is_cuda)
+        H.release(lease, st)
+
     def _capture(self, ws, key):
         """Capture the whole step (RNG draws included) into a hipGraph.  The graph bakes in
         cur_capacity (the randint bound), so it is re-captured while the ring is still filling."""
@@ -328,25 +425,31 @@ class PQLVLearner:
             self._draw_and_step(ws)
         torch.cuda.current_stream(self.device).wait_stream(s)
         self._restore(snap)
-        g = torch.cuda.CUDAGraph()
-        g_post = None
-        # PQL_DP_GRAPH_COLLECTIVE=1 (opt-in, rehearsed with a 1-rank RCCL group only): capture the all-reduce inside ONE graph
-        # instead of splitting the step around an eager collective
-        if not self.dp or os.environ.get("PQL_DP_GRAPH_COLLECTIVE"):
-            with torch.cuda.graph(g):
+        g, g_post = self._new_graph(), None
+        # PQL_DP_GRAPH_COLLECTIVE=1 (opt-in, RCCL only, rehearsed with a 1-rank group only): capture the all-reduce inside
+        # ONE graph instead of splitting the step around an eager collective
+        if not self.dp or graph_collective_enabled(self.pg):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._draw_and_step(ws)
         else:   # two graphs around the RCCL all-reduce (kept eager: no collective is ever captured)
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self._draw_and_step(ws, upto_backward=True)
-            g_post = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_post):
+            g_post = self._new_graph()
+            with torch.cuda.graph(g_post, capture_error_mode="thread_local"):
                 self._step_post(ws)
         self._restore(snap)  # capture does not execute, but keep state exactly as before
         self._graph, self._graph_post, self._graph_key = g, g_post, key
 
+    def _new_graph(self):
+        g = torch.cuda.CUDAGraph()
+        if self.gen is not None:    # a private generator takes part in capture only when registered with the graph
+            g.register_generator_state(self.gen)
+        return g
+
     def _snapshot(self):
         return [t.clone() for t in (self.critic.arena.data, self.critic_target.arena.data, self.opt.m, self.opt.v,
-                                    self.opt.step, self.loss_ring)], torch.cuda.get_rng_state(self.device)
+                                    self.opt.step, self.loss_ring)], \
+            (self.gen.get_state() if self.gen is not None else torch.cuda.get_rng_state(self.device))
 
     def _restore(self, snap):
         tensors, rng = snap
@@ -354,7 +457,10 @@ class PQLVLearner:
                              self.loss_ring), tensors):
             dst.copy_(src)
         self.repack()
-        torch.cuda.set_rng_state(rng, self.device)
+        if self.gen is not None:
+            self.gen.set_state(rng)
+        else:
+            torch.cuda.set_rng_state(rng, self.device)
 
     # ------------------------------------------------------------------------------------------
     def loss_mean(self):
@@ -367,37 +473,42 @@ class PQLVLearner:
             self.loss_tracker.update(vals[t % LOSS_RING])
         return m
 
-    def set_actor(self, actor):
-        """Adopt new policy weights.  A pql_amd actor on another GPU is copied arena-to-arena (peer copy
-        over xGMI) into a resident replica instead of re-materialising a module."""
+    def set_actor(self, actor, home=None):
+        """Adopt new policy weights into the resident replica: a fenced flat-arena copy on this learner's stream; from
+        another GPU through the copy streams (peer copy over xGMI) -- the reference pickles the module through Ray."""
         if self.actor is None or self.actor.layout.dims != actor.layout.dims:
-            self.actor = deepcopy(actor).to(self.device)
+            st = torch.cuda.current_stream(self.device)
+            with H.LOCK:
+                lease = H.acquire(actor, st, home)
+                self.actor = deepcopy(actor).to(self.device)
+                H.release(lease, st)
+            self.actor.requires_grad_(False)
             self.pk_actor = PackedWeights(self.actor.layout, self.device) if self._fused else None
         elif actor is not self.actor:
-            self.actor.arena.data.copy_(actor.arena.data, non_blocking=True)
+            adopt_arena(self.actor, actor, self.device, home)
         if self.pk_actor is not None:
             self.pk_actor.refresh(self.actor.arena.data)
 
     @torch.no_grad()
     def update(self, actor, trajectory, normalize_tuple, sleep_time):
-        with torch.cuda.device(self.device), self._on_stream():
-            if self.stream is not None:   # fence: the producer's work (rollout stream) must be visible first
-                self.stream.wait_stream(torch.cuda.default_stream(self.device) if getattr(self, "producer_stream", None) is None
-                                        else self.producer_stream)
-                for t in trajectory:
-                    if t.is_cuda:
-                        t.record_stream(self.stream)
-            self.set_actor(actor)
-            self.memory.add_to_buffer(trajectory)
-            self.normalize_tuple = resident_norm(self, normalize_tuple)
+        """pql_v_learner.py:117-122.  Everything is enqueued on this learner's stream behind event fences
+        (pql_amd.utils.handoff): the stream waits for the producers of `actor`, `trajectory` and the statistics, the
+        producers' buffers are released when the copies / the ring insert have read them, and the critic handed back
+        is a snapshot (double-buffered) that later optimiser steps do not touch."""
+        home = torch.cuda.current_stream(self.device)   # the caller's stream, before we switch to ours
+        with self._lock, torch.cuda.device(self.device), self._on_stream():
+            st = torch.cuda.current_stream(self.device)
+            self.set_actor(actor, home)
+            with H.LOCK:
+                lease = H.acquire(trajectory, st, home)
+                self.memory.add_to_buffer(trajectory)
+                H.release(lease, st)
+            self.normalize_tuple = resident_norm(self, normalize_tuple, home)
             loss = self._lagged.poll(self.update_count)
-        self.sleep_time = sleep_time
-        return self.critic, loss, self.update_count
+            self.sleep_time = sleep_time
+            return self._published(), loss, self.update_count
 
 
-def asyn_v_learner(learner, cfg, stop_event=None):
+def asyn_v_learner(learner, cfg, stop_event=None, max_in_flight=2):
     """Free-running pump (reference: a Ray task looping forever, :136-141).  Run it in a thread."""
-    while stop_event is None or not stop_event.is_set():
-        sleep_time = learner.learn()
-        if sleep_time:
-            time.sleep(sleep_time)
+    pump(learner, stop_event, max_in_flight)

@@ -231,6 +231,26 @@ class FusedMLP(nn.Module):
     def num_params(self):
         return self.layout.count_params()
 
+    def __deepcopy__(self, memo):
+        """deepcopy of a *published* snapshot (pql_amd.utils.handoff.ArenaPublisher: what a learner's `update()` returns
+        when it runs on its own stream) must not read the arena before the snapshot has been written, and must keep the
+        publisher from overwriting it mid-copy: fence the copier's stream on both sides.  A plain module copies as usual."""
+        from copy import deepcopy
+        from pql_amd.utils import handoff as H
+        lease = H.lease_of(self)
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        with H.LOCK:
+            st = torch.cuda.current_stream(self.arena.device) if (lease is not None and self.arena.is_cuda) else None
+            if st is not None and lease.ready is not None:
+                st.wait_event(lease.ready)
+            for k, v in self.__dict__.items():
+                if k != "_pql_lease":
+                    new.__dict__[k] = deepcopy(v, memo)
+            if st is not None:
+                H.release(lease, st)
+        return new
+
     def _run(self, x):
         return FusedMlpFn.apply(x, self.arena, self.layout, self.out_act)
 

@@ -32,10 +32,22 @@ class NStepReplay:
         self.win_ld = int(L.lib.pqlk_replay_rec_ld(self.O, self.A))
         self.window = torch.zeros((self.num_envs, self.nstep, self.win_ld), dtype=torch.float32, device=self.device)
 
+    def rows_out(self, T):
+        """Rows the next add_to_buffer call with horizon T emits."""
+        if self.nstep <= 1:
+            return T * self.num_envs
+        return max(T - max(self.nstep - 1 - self.nstep_count, 0), 0) * self.num_envs
+
     @torch.no_grad()
-    def add_to_buffer(self, obs, actions, rewards, next_obs, dones):
+    def add_to_buffer(self, obs, actions, rewards, next_obs, dones, out=None):
+        """`out`: optional preallocated (M,O),(M,A),(M,1),(M,O),(M,1) fp32 destination (a producer that hands its blocks to
+        other streams keeps them double-buffered instead of allocating per call)."""
         if self.nstep <= 1:  # pass-through (nstep_replay.py:66-67)
-            return obs, actions, rewards, next_obs, dones
+            if out is None:
+                return obs, actions, rewards, next_obs, dones
+            for dst, src in zip(out, (obs, actions, rewards, next_obs, dones)):
+                dst.copy_(src.reshape(dst.shape))
+            return out
         N, O, A = self.num_envs, self.O, self.A
         T = obs.shape[1]
         f = dict(dtype=torch.float32, device=self.device)
@@ -50,8 +62,11 @@ class NStepReplay:
             # reference: torch.cat([]) raises when the first call is shorter than the window (:65)
             raise RuntimeError("NStepReplay.add_to_buffer: no complete n-step window yet (first call needs T >= nstep)")
         M = steps_out * N
-        out = (torch.empty((M, O), **f), torch.empty((M, A), **f), torch.empty((M, 1), **f), torch.empty((M, O), **f),
-               torch.empty((M, 1), **f))
+        if out is None:
+            out = (torch.empty((M, O), **f), torch.empty((M, A), **f), torch.empty((M, 1), **f), torch.empty((M, O), **f),
+                   torch.empty((M, 1), **f))
+        elif tuple(out[0].shape) != (M, O) or tuple(out[1].shape) != (M, A) or any(not t.is_contiguous() for t in out):
+            raise L.PqlkError(f"NStepReplay.add_to_buffer: `out` must be contiguous blocks of {M} rows")
         rows = C.c_int64(0)
         with torch.cuda.device(self.device):
             L.check(L.lib.pqlk_nstep_push_emit(L.ptr(self.window), N, self.nstep, O, A, self.nstep_count, T,

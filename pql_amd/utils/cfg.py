@@ -73,8 +73,15 @@ def _load_file(path: Path, group_choices=None):
             if option is None:
                 out.setdefault(group, None)
                 continue
-            sub = _load_file(path.parent / group / f"{option}.yaml" if not str(option).endswith(".yaml")
-                             else path.parent / group / option)
+            fpath = (path.parent / group / f"{option}.yaml" if not str(option).endswith(".yaml")
+                     else path.parent / group / option)
+            if group == "task" and not fpath.exists():
+                # the reference's `task=<IsaacGymEnvs task name>` (pql/cfg/default.yaml:7-9 + the isaacgymenvs search
+                # path): here every task is the synthetic vectorised env with that task's shapes
+                sub = _load_file(path.parent / group / "synthetic.yaml")
+                sub["name"] = str(option)
+            else:
+                sub = _load_file(fpath)
             out[group] = _merge(out.get(group) or {}, sub)
     if not self_done:
         _merge(out, data)

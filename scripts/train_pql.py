@@ -3,18 +3,25 @@
 (`python scripts/train_pql.py task=AllegroHand algo.distl=True algo.num_gpus=1 ...`), same cfg keys, same
 metric names; the Isaac-Gym rollout is replaced by the synthetic vectorised env (task.name picks the shapes).
 
-Orchestration differs by design (SURVEY 3.1 -> MI355X): instead of three Ray processes exchanging pickled
-nn.Modules through the object store, ONE process per GPU issues the sim / V-learner / P-learner launch
-sequences itself, at exactly the ratios the reference's sleep-based controller (train_pql.py:127-158) tries
-to converge to: `critic_sample_ratio` V-steps and `critic_sample_ratio / critic_actor_ratio` P-steps per env
-iteration.  Weights move between the components as flat arena copies (peer-to-peer over xGMI when the
-learners sit on another GPU); transitions go straight from the n-step kernel's output into the replay rings.
-With torchrun (WORLD_SIZE > 1) the env axis and the replay shard data-parallel and gradients are
-all-reduced over RCCL.
+Orchestration (SURVEY 3.1 -> MI355X): instead of three Ray processes exchanging pickled nn.Modules through the
+object store, ONE process drives three launch queues (HIP streams; with `algo.num_gpus=2` the learners' queues sit
+on another GPU and every hand-off crosses xGMI through dedicated copy streams).  Hand-offs are event-fenced and
+double-buffered (pql_amd/utils/handoff.py); the host never waits for the GPU.  Two ways to keep the components at
+the design ratios 1 : critic_sample_ratio : critic_sample_ratio / critic_actor_ratio:
+
+  algo.async_learners=False (default)  the loop itself issues exactly `critic_sample_ratio` V-steps and the matching
+      P-steps per rollout iteration -- the fixed point the reference's controller converges to, without sleeping;
+  algo.async_learners=True             the reference's topology: the learners free-run in threads (`asyn_v_learner`
+      / `asyn_p_learner`) and the reference's sliding-window controller (train_pql.py:127-158, here
+      pql_amd.utils.ratio_control.RatioController) tells whoever is too fast how long to sleep per unit.
+
+With torchrun (WORLD_SIZE > 1) the env axis and the replay shard data-parallel and gradients are all-reduced over
+RCCL (fixed-ratio loop only: free-running ranks would issue their collectives out of step).
 """
 import os
 import sys
-from copy import deepcopy
+import threading
+import time
 from itertools import count
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,13 +30,14 @@ import torch  # noqa: E402
 
 import pql_amd  # noqa: E402,F401
 from pql_amd.algo.pql_actor import PQLActor  # noqa: E402
-from pql_amd.algo.pql_p_learner import PQLPLearner  # noqa: E402
-from pql_amd.algo.pql_v_learner import PQLVLearner  # noqa: E402
+from pql_amd.algo.pql_p_learner import PQLPLearner, asyn_p_learner  # noqa: E402
+from pql_amd.algo.pql_v_learner import PQLVLearner, asyn_v_learner  # noqa: E402
 from pql_amd.envs.synthetic import create_task_env  # noqa: E402
 from pql_amd.utils.cfg import load_cfg  # noqa: E402
 from pql_amd.utils.common import capture_keyboard_interrupt, preprocess_cfg, set_random_seed  # noqa: E402
 from pql_amd.utils.evaluator import Evaluator  # noqa: E402
 from pql_amd.utils.logger import MetricLogger  # noqa: E402
+from pql_amd.utils.ratio_control import RatioController  # noqa: E402
 
 
 def agree_to_stop(stop, pg, device):
@@ -78,7 +86,7 @@ def main(cfg):
             pql_actor.obs_rms.pg = pg
     critic, critic_update_times, critic_loss = v_learner.start()
     actor, actor_update_times, actor_loss = p_learner.start()
-    pql_actor.actor = deepcopy(actor).to(sim_device)
+    pql_actor.set_actor(actor)
 
     logger = MetricLogger(cfg.logging.get("jsonl") if cfg.get("logging") else None) if rank == 0 else None
     global_steps = 0
@@ -88,21 +96,45 @@ def main(cfg):
     p_data, v_data, steps = pql_actor.explore_env(env, cfg.algo.warm_up, random=True)
     global_steps += steps * world
     rms = (lambda dev: pql_actor.obs_rms.get_states(dev)) if pql_actor.obs_rms is not None else (lambda dev: None)
-    v_learner.update(actor, v_data, rms(v_dev), 0)
-    p_learner.update(critic, p_data, rms(p_dev), 0)
+    critic, critic_loss, critic_update_times = v_learner.update(actor, v_data, rms(v_dev), 0)
+    actor, actor_loss, actor_update_times = p_learner.update(critic, p_data, rms(p_dev), 0)
+
+    free_running = bool(cfg.algo.get("async_learners", False))
+    if free_running and world > 1:
+        raise ValueError("algo.async_learners=True is single-process only: data-parallel ranks must issue their "
+                         "gradient all-reduces in step, which the fixed-ratio loop guarantees")
+    stop_learners, threads, ctl = threading.Event(), [], None
+    if free_running:
+        # the reference's learners are separate processes with their own RNG streams
+        v_learner.use_private_rng(cfg.seed + 1)
+        p_learner.use_private_rng(cfg.seed + 2)
+        depth = int(cfg.algo.get("max_in_flight", 2))
+        threads = [threading.Thread(target=asyn_v_learner, args=(v_learner, cfg, stop_learners, depth), daemon=True),
+                   threading.Thread(target=asyn_p_learner, args=(p_learner, cfg, stop_learners, depth), daemon=True)]
+        for t in threads:
+            t.start()
+        ctl = RatioController(cfg.algo.critic_sample_ratio, cfg.algo.critic_actor_ratio, critic_update_times, actor_update_times)
 
     v_per_iter = int(cfg.algo.critic_sample_ratio)
     p_every = int(cfg.algo.critic_actor_ratio)
+    critic_wait = actor_wait = 0
     for iter_t in count():
         p_data, v_data, steps = pql_actor.explore_env(env, cfg.algo.horizon_len, random=False)
         global_steps += steps * world
-        _, critic_loss, critic_update_times = v_learner.update(pql_actor.actor, v_data, rms(v_dev), 0)
-        _, actor_loss, actor_update_times = p_learner.update(v_learner.critic, p_data, rms(p_dev), 0)
-        pql_actor.actor.arena.data.copy_(p_learner.actor.arena.data, non_blocking=True)
-        for k in range(v_per_iter):
-            v_learner.learn()
-            if k % p_every == p_every - 1:
-                p_learner.learn()
+        # hand-offs (train_pql.py:111-119): newest policy + transitions -> V-learner, newest critic + obs -> P-learner,
+        # newest policy -> rollout replica.  What comes back are snapshots, so nobody reads an arena that is being stepped.
+        critic, critic_loss, critic_update_times = v_learner.update(actor, v_data, rms(v_dev), critic_wait)
+        actor, actor_loss, actor_update_times = p_learner.update(critic, p_data, rms(p_dev), actor_wait)
+        pql_actor.set_actor(actor)
+        if free_running:
+            sim_wait, critic_wait, actor_wait = ctl.observe(critic_update_times, actor_update_times)
+            if sim_wait > 0:
+                time.sleep(sim_wait)
+        else:
+            for k in range(v_per_iter):
+                v_learner.learn()
+                if k % p_every == p_every - 1:
+                    p_learner.learn()
         if rank == 0 and evaluator.parent.poll():
             logger.log(evaluator.parent.recv(), global_steps)
         if rank == 0 and iter_t % cfg.algo.log_freq == 0:
@@ -115,12 +147,15 @@ def main(cfg):
             if iter_t % cfg.algo.eval_freq == 0:
                 logger.table(global_steps, log_info)
         if rank == 0 and iter_t % cfg.algo.eval_freq == 0:
-            evaluator.eval_policy(pql_actor.actor, v_learner.critic, normalizer=pql_actor.obs_rms, step=global_steps)
+            evaluator.eval_policy(pql_actor.actor, critic, normalizer=pql_actor.obs_rms, step=global_steps)
         stop = evaluator.check_if_should_stop(global_steps)
         if cfg.max_step is None:
             stop = agree_to_stop(stop, pg, sim_device)
         if stop:
             break
+    stop_learners.set()
+    for t in threads:
+        t.join()
     if rank == 0:
         while evaluator.parent.pending():   # evaluations still in flight when training stops
             logger.log(evaluator.parent.recv(), global_steps)
@@ -128,7 +163,9 @@ def main(cfg):
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.destroy_process_group()
-    return dict(global_steps=global_steps, critic_updates=v_learner.update_count, actor_updates=p_learner.update_count)
+    return dict(global_steps=global_steps, critic_updates=v_learner.update_count, actor_updates=p_learner.update_count,
+                rollout_iterations=iter_t + 1, waits=(None if ctl is None else (ctl.sim_wait_time, ctl.critic_wait_time,
+                                                                                 ctl.actor_wait_time)))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,194 @@
+"""The measured mode (learners on their own HIP streams, steps replayed from hipGraphs) and the two-GPU hand-off path,
+checked against the serial path.  `bench.py` reports `value` in streams + graph mode, so that exact schedule object is what
+runs here.  Run with `pytest -m gpu`.
+
+What is asserted
+  * bit-identity: N slices of the 1 : 4 : 8 schedule (rollout -> n-step -> ring inserts -> weight hand-offs -> V / P steps)
+    give the SAME parameter arenas, optimiser state, replay rings and observation statistics whether every launch sits on
+    one stream (no graph) or V-learner / P-learner / rollout run on three streams with hipGraph replay -- and also when every
+    hand-off is forced through the copy streams + landing blocks of the two-GPU layout (both "devices" = cuda:0);
+  * no torn hand-off: with the learners free-running in threads, every critic snapshot a consumer reads equals the live
+    arena at a whole optimiser step (checksum taken on the owner's stream at publish time);
+  * the reference's topology (threads + ratio controller) keeps the update counts near 1 : P : V = 1 : 4 : 8.
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _args(**kw):
+    a = dict(task="Toy", num_envs=64, batch=256, replay=4096, nstep=3, hidden="512,256,128", distl=False, no_graph=False,
+             no_streams=False, no_fused=False)
+    a.update(kw)
+    return argparse.Namespace(**a)
+
+
+def _state(actor, v, p):
+    torch.cuda.synchronize()
+    return dict(critic=v.critic.arena.data.clone(), target=v.critic_target.arena.data.clone(), adam_m=v.opt.m.clone(),
+                adam_v=v.opt.v.clone(), v_step=v.opt.step.clone(), policy=p.actor.arena.data.clone(), p_m=p.opt.m.clone(),
+                p_step=p.opt.step.clone(), v_ring=v.memory.ring.records.clone(), p_ring=p.ring.records.clone(),
+                v_loss=v.loss_ring.clone(), p_loss=p.loss_ring.clone(), rollout_policy=actor.actor.arena.data.clone(),
+                rms_mean=actor.obs_rms.mean.clone(), rms_var=actor.obs_rms.var.clone(), obs=actor.obs.clone(),
+                v_replica_of_policy=v.actor.arena.data.clone(), p_replica_of_critic=p.critic.arena.data.clone())
+
+
+def _run_schedule(steps, force_ship=False, **kw):
+    from pql_amd.utils import handoff
+    bench = _bench()
+    handoff.FORCE_SHIP = force_ship
+    try:
+        dev = torch.device("cuda:0")
+        torch.manual_seed(1234)
+        args = _args(**kw)
+        cfg, env, actor, v, p = bench.build_system(args, 0, 1, dev, None)
+        critic, policy = bench.prefill(actor, v, p, env, cfg, args, dev)
+        sched = bench.Schedule(actor, v, p, env, cfg, dev, critic, policy)
+        for _ in range(steps):
+            sched.step()
+        out = _state(actor, v, p)
+        out["counts"] = (v.update_count, p.update_count, sched.global_steps)
+        return out
+    finally:
+        handoff.FORCE_SHIP = False
+
+
+@pytest.mark.parametrize("distl", [False, True])
+def test_streams_and_graphs_are_bit_identical_to_the_serial_schedule(distl):
+    """The mode BENCH is measured in vs the plain one-stream eager path, 48 slices = 6 rollout iterations with hand-offs."""
+    serial = _run_schedule(48, no_graph=True, no_streams=True, distl=distl)
+    fast = _run_schedule(48, distl=distl)
+    assert serial["counts"] == fast["counts"] == (48, 24, 6 * 64)
+    assert int(serial["v_step"]) == 48 and int(serial["p_step"]) == 24
+    for k, a in serial.items():
+        if k != "counts":
+            assert torch.equal(a, fast[k]), k
+    # and the hand-offs did move: the rollout replica holds a policy that has been stepped
+    assert not torch.equal(fast["rollout_policy"], _run_schedule(0)["rollout_policy"])
+
+
+def test_two_gpu_hand_off_path_rehearsed_on_one_card_is_bit_identical():
+    """cfg #3 (simulator GPU0, learners GPU1) moves every block through a Shipper: copy streams, landing blocks, lease
+    events.  With both devices = cuda:0 the same code must reproduce the serial arenas bit for bit."""
+    serial = _run_schedule(40, no_graph=True, no_streams=True)
+    shipped = _run_schedule(40, force_ship=True)
+    for k, a in serial.items():
+        if k != "counts":
+            assert torch.equal(a, shipped[k]), k
+    eager_streams = _run_schedule(40, force_ship=True, no_graph=True)
+    for k, a in serial.items():
+        if k != "counts":
+            assert torch.equal(a, eager_streams[k]), k
+
+
+def test_full_size_schedule_streams_graph_vs_serial():
+    """Same bit-identity at BASELINE configs[1] shapes (obs 88 / act 16, batch 8192, [512,512,256]), smaller ring."""
+    kw = dict(task="AllegroHand", num_envs=4096, batch=8192, replay=65536, hidden="512,512,256")
+    serial = _run_schedule(24, no_graph=True, no_streams=True, **kw)
+    fast = _run_schedule(24, **kw)
+    for k, a in serial.items():
+        if k != "counts":
+            assert torch.equal(a, fast[k]), k
+
+
+@pytest.mark.parametrize("force_ship", [False, True])
+def test_free_running_learners_never_hand_out_a_torn_arena(force_ship):
+    """Learner threads step continuously while the main thread keeps handing data over.  Every snapshot returned by
+    `update()` must equal the live arena as it was between two optimiser steps: the owner records a checksum of the live
+    arena right behind the snapshot copy (same stream), the consumer checksums the snapshot behind its acquire fence."""
+    from pql_amd.algo.pql_p_learner import asyn_p_learner
+    from pql_amd.algo.pql_v_learner import asyn_v_learner
+    from pql_amd.utils import handoff as H
+    bench = _bench()
+    H.FORCE_SHIP = force_ship
+    stop = threading.Event()
+    threads = []
+    try:
+        dev = torch.device("cuda:0")
+        torch.manual_seed(7)
+        args = _args(task="AllegroHand", num_envs=256, batch=2048, replay=16384)
+        cfg, env, actor, v, p = bench.build_system(args, 0, 1, dev, None)
+        critic, policy = bench.prefill(actor, v, p, env, cfg, args, dev)
+        owner_sums = {"v": [], "p": []}
+        for tag, learner, live in (("v", v, v.critic), ("p", p, p.actor)):
+            def wrap(orig=learner._pub.publish, live=live, tag=tag):
+                snap = orig()
+                owner_sums[tag].append(live.arena.data.double().sum())   # current stream = the owner's, right behind the copy
+                snap._test_index = len(owner_sums[tag]) - 1
+                return snap
+            learner._pub.publish = wrap
+        v.use_private_rng(11); p.use_private_rng(12)
+        threads = [threading.Thread(target=asyn_v_learner, args=(v, cfg, stop), daemon=True),
+                   threading.Thread(target=asyn_p_learner, args=(p, cfg, stop), daemon=True)]
+        for t in threads:
+            t.start()
+        checker = torch.cuda.Stream(dev)
+        seen = []
+        rms = actor.obs_rms
+        for it in range(60):
+            p_data, v_data, _ = actor.explore_env(env, 1, random=False)
+            critic, _, n_v = v.update(policy, v_data, rms.get_states(dev), 0)
+            policy, _, n_p = p.update(critic, p_data, rms.get_states(dev), 0)
+            actor.set_actor(policy)
+            for tag, snap in (("v", critic), ("p", policy)):
+                with H.LOCK:
+                    lease = H.acquire(snap, checker)
+                    with torch.cuda.stream(checker):
+                        seen.append((tag, snap._test_index, snap.arena.data.double().sum()))
+                    H.release(lease, checker)
+            time.sleep(0.001)
+        stop.set()
+        for t in threads:
+            t.join(timeout=60)
+        torch.cuda.synchronize()
+        assert v.update_count > 20 and p.update_count > 10, (v.update_count, p.update_count)
+        assert len(seen) == 120
+        for tag, i, s in seen:
+            assert s.item() == owner_sums[tag][i].item(), (tag, i)
+        # the learners did step between hand-offs (the checksums are not all one value)
+        assert len({owner_sums["v"][i].item() for t, i, _ in seen if t == "v"}) > 5
+        assert torch.isfinite(v.critic.arena.data).all() and torch.isfinite(p.actor.arena.data).all()
+    finally:
+        stop.set()
+        for t in threads:
+            t.join(timeout=60)
+        H.FORCE_SHIP = False
+
+
+def test_train_pql_free_running_with_ratio_controller():
+    """scripts/train_pql.py with algo.async_learners=True: threads + the reference's controller.  The control law needs
+    thousands of iterations to settle exactly (tests/test_host_cpu.py runs it closed-loop in virtual time); here the real
+    threads must run, stop cleanly and land near the design ratios."""
+    from pql_amd.utils.cfg import load_cfg
+    spec = importlib.util.spec_from_file_location("train_pql", os.path.join(ROOT, "scripts", "train_pql.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cfg = load_cfg(["task=AllegroHand", "num_envs=1024", "algo.batch_size=4096", "algo.memory_size=200000", "algo.num_gpus=1",
+                    "max_step=1500000", "algo.async_learners=True", "algo.eval_freq=100000", "algo.log_freq=100000"])
+    out = mod.main(cfg)
+    iters = out["rollout_iterations"]
+    assert iters > 1000
+    v_per, p_per = out["critic_updates"] / iters, out["actor_updates"] / iters
+    assert 4.0 < v_per < 12.0, out
+    assert 1.5 < out["critic_updates"] / out["actor_updates"] < 2.7, out
+    assert p_per > 1.5, out

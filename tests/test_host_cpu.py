@@ -273,3 +273,140 @@ def test_c_abi_reports_argument_errors_as_codes():
     assert lib.pqlk_synth_env_step(0, 8, 2, 1, 0, 1, 0.01, P, P, P, P, None) == E_SHAPE
     for code in (E_NULL, E_SHAPE, 3, E_ALIGN, E_UNSUPPORTED, 6):
         assert len(lib.pqlk_strerror(code)) > 2
+
+
+# --------------------------------------------------------------------------- the `pql` name
+def test_pql_alias_package_resolves_to_the_same_modules():
+    """north_star: "keeps the pql.algo / scripts/train_pql.py entry points".  Every name SURVEY 8(b) lists must import
+    from `pql.*` and be the SAME object as under `pql_amd.*` (one class, two names)."""
+    import importlib
+    import pql
+    import pql_amd
+    assert pql.LIB_PATH == pql_amd.LIB_PATH and (pql.LIB_PATH / "cfg" / "default.yaml").exists()
+    wanted = {
+        "pql.algo.pql_actor": ["PQLActor"],
+        "pql.algo.pql_v_learner": ["PQLVLearner", "asyn_v_learner"],
+        "pql.algo.pql_p_learner": ["PQLPLearner", "asyn_p_learner"],
+        "pql.algo.ddpg": ["AgentDDPG"], "pql.algo.sac": ["AgentSAC"], "pql.algo.crossQ": ["AgentCrossQ"],
+        "pql.replay.simple_replay": ["ReplayBuffer", "create_buffer"],
+        "pql.replay.nstep_replay": ["NStepReplay"],
+        "pql.models.mlp": ["MLPNet", "TanhMLPPolicy", "DoubleQ", "DistributionalDoubleQ", "TanhDiagGaussianMLPPolicy"],
+        "pql.utils.common": ["Tracker", "normalize", "load_class_from_path", "set_random_seed", "preprocess_cfg",
+                             "capture_keyboard_interrupt", "handle_timeout"],
+        "pql.utils.torch_util": ["RunningMeanStd", "soft_update"],
+        "pql.utils.noise": ["add_normal_noise", "add_mixed_normal_noise"],
+        "pql.utils.distl_util": ["projection"],
+        "pql.utils.schedule_util": ["LinearSchedule", "ExponentialSchedule"],
+        "pql.utils.evaluator": ["Evaluator"],
+        "pql.utils.model_util": ["save_model", "load_model"],
+        "pql.utils.isaacgym_util": ["create_task_env"],
+    }
+    for mod_name, names in wanted.items():
+        mod = importlib.import_module(mod_name)
+        real = importlib.import_module(mod.__name__)
+        assert mod is real and mod.__name__.startswith("pql_amd."), mod_name
+        for n in names:
+            assert hasattr(mod, n), f"{mod_name}.{n}"
+    from pql.models import model_name_to_path
+    from pql.algo import alg_name_to_path
+    assert {"DoubleQ", "DistributionalDoubleQ", "TanhMLPPolicy"} <= set(model_name_to_path)
+    assert "AgentDDPG" in alg_name_to_path
+    with pytest.raises(ModuleNotFoundError):
+        importlib.import_module("pql.no_such_module")
+
+
+def test_reference_cli_task_names_compose():
+    """`task=<IsaacGymEnvs name>` (pql/cfg/default.yaml:7-9) composes onto the synthetic env with that task's shapes;
+    the fast path (graph + own streams) is the default."""
+    from pql_amd.envs.synthetic import create_task_env
+    from pql_amd.utils.cfg import load_cfg
+    for name, shape in (("AllegroHand", (88, 16)), ("ShadowHand", (211, 20)), ("Humanoid", (108, 21)), ("Ant", (60, 8))):
+        cfg = load_cfg([f"task={name}", "device=cpu", "num_envs=4"])
+        assert cfg.task.name == name and cfg.algo.graph is True and cfg.algo.streams is True
+        env = create_task_env(cfg)
+        assert (env.observation_space.shape[0], env.action_space.shape[0]) == shape
+    assert load_cfg([]).algo.async_learners is False
+
+
+# --------------------------------------------------------------------------- a25 ratio controller
+def test_ratio_controller_matches_the_reference_law():
+    from oracle.pql_ref_cpu import ratio_control_ref
+    from pql_amd.utils.ratio_control import RatioController
+    rng = np.random.default_rng(0)
+    for trial in range(4):
+        n = 400
+        dt = rng.uniform(0.5e-3, 3e-3, n)
+        t = np.cumsum(dt)
+        cri = np.cumsum(rng.integers(0 if trial == 3 else 1, 14, n))      # trial 3: windows where a counter stalls
+        act = np.cumsum(rng.integers(0 if trial == 3 else 1, 7, n))
+        if trial == 3:
+            cri[:15] = 0; act[:15] = 0
+        obs = [(float(a), int(b), int(c)) for a, b, c in zip(t, cri, act)]
+        want = ratio_control_ref(obs, 8, 2)
+        now = [0.0]
+        ctl = RatioController(8, 2, clock=lambda: now[0])
+        got = []
+        for (t_i, c, a) in obs:
+            now[0] = t_i
+            got.append(ctl.observe(c, a))
+        np.testing.assert_allclose(np.array(got, dtype=np.float64), np.array(want, dtype=np.float64), rtol=0, atol=0)
+
+
+def test_ratio_controller_closed_loop_reaches_design_ratios():
+    """Closed loop in virtual time: three components with fixed unit costs, learners sleeping what they are told.  The law is
+    an integrating controller over a 100-iteration window, so it needs a few thousand iterations (as in the reference)."""
+    from pql_amd.utils.ratio_control import RatioController
+    for ts, tv, tp in ((1e-3, 0.15e-3, 0.15e-3), (0.5e-3, 0.7e-3, 0.6e-3), (4e-3, 0.1e-3, 0.1e-3)):
+        now = [0.0]
+        ctl = RatioController(8, 2, clock=lambda: now[0])
+        v_t = p_t = 0.0
+        v_n = p_n = 0
+        cw = aw = 0.0
+        hist = []
+        for it in range(3000):
+            end = now[0] + ts
+            while v_t + tv + cw <= end:
+                v_t += tv + cw; v_n += 1
+            while p_t + tp + aw <= end:
+                p_t += tp + aw; p_n += 1
+            now[0] = end
+            sw, cw, aw = ctl.observe(v_n, p_n)
+            now[0] += sw
+            hist.append((it + 1, v_n, p_n))
+        a, b = hist[len(hist) // 2], hist[-1]
+        assert abs((b[1] - a[1]) / (b[0] - a[0]) - 8) < 0.8, (ts, tv, tp)
+        assert abs((b[1] - a[1]) / (b[2] - a[2]) - 2) < 0.1, (ts, tv, tp)
+
+
+# --------------------------------------------------------------------------- trackers (ADVICE r1)
+def test_device_tracker_keeps_the_last_max_len_values_like_the_reference_deque():
+    """More finished episodes in one step than the window holds (tracker_len 100 vs 4096 envs): deque.extend keeps the
+    LAST max_len values; the scatter form must keep exactly those (and be deterministic)."""
+    import torch
+    from pql_amd.algo.pql_actor import DeviceTracker
+    from pql_amd.utils.common import Tracker
+    rng = np.random.default_rng(3)
+    dt, ref = DeviceTracker(10, "cpu"), Tracker(10)
+    for step in range(12):
+        n = 64
+        vals = torch.from_numpy(rng.normal(size=n).astype(np.float32))
+        p = (0.02, 0.5, 0.9, 0.0)[step % 4]
+        mask = torch.from_numpy(rng.random(n) < p)
+        dt.update(vals, mask)
+        ref.update(vals[mask])
+        assert sorted(dt.ring[:10].tolist()) == pytest.approx(sorted(float(x) for x in ref.moving_average))
+        assert dt.mean() == pytest.approx(float(ref.mean()), rel=1e-6, abs=1e-7)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` from a bare shell starts N ranks itself -- and fails loudly, before any GPU call, when the
+    box has fewer devices (it used to benchmark one GPU and print n_gpus: 1)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    n = torch.cuda.device_count() + 2
+    for extra in ([], ["--layout", "split2"] if n == 2 else []):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), *extra], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)

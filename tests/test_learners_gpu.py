@@ -18,10 +18,14 @@ def dev():
     return torch.device("cuda:0")
 
 
-def make_cfg(distl=False, B=64, memory=400, hidden=None, graph=False, nstep=3):
+def make_cfg(distl=False, B=64, memory=400, hidden=None, graph=False, nstep=3, streams=False, task=None):
+    """streams=False: learner work on the caller's stream (results readable right after the call); streams=True: the
+    learners' own HIP streams with event-fenced hand-offs -- read results after `learner.synchronize()`."""
     from pql_amd.utils.cfg import load_cfg
     ov = [f"algo.batch_size={B}", f"algo.memory_size={memory}", f"algo.distl={distl}", "algo.v_learner_gpu=0",
-          "algo.p_learner_gpu=0", "algo.num_gpus=1", f"algo.graph={graph}", f"algo.nstep={nstep}"]
+          "algo.p_learner_gpu=0", "algo.num_gpus=1", f"algo.graph={graph}", f"algo.nstep={nstep}", f"algo.streams={streams}"]
+    if task:
+        ov.append(f"task={task}")
     cfg = load_cfg(ov)
     cfg.algo.hidden_layers = hidden
     return cfg
@@ -42,20 +46,26 @@ def _check_module(module, g, prefix, rtol=5e-5, atol=5e-7):
                                    err_msg=prefix + key)
 
 
+@pytest.mark.parametrize("streams", [False, True])
 @pytest.mark.parametrize("distl", [False, True])
-def test_v_learner_golden_trace(golden, dev, distl):
+def test_v_learner_golden_trace(golden, dev, distl, streams):
     from pql_amd.algo.pql_v_learner import PQLVLearner
     from pql_amd.models.mlp import TanhMLPPolicy
     g = golden("learners"); tag = "vd" if distl else "v"; O, A = 8, 2
-    v = PQLVLearner((O,), A, make_cfg(distl))
+    v = PQLVLearner((O,), A, make_cfg(distl, streams=streams))
     v.critic.load_state_dict(_sd(dd.doubleq_state(O, A, 51 if distl else 1, 31 if distl else 21)))
     v.critic_target.arena.data.copy_(v.critic.arena.data)
     actor = TanhMLPPolicy((O,), A).to(dev); actor.load_state_dict(_sd(dd.mlp_state(O, A, 11)))
     norm = (T(g["learner_norm_mean"]).to(dev), T(g["learner_norm_var"]).to(dev), 1e-4)
     critic, loss_mean, count = v.update(actor, tuple(t.to(dev) for t in _fill(O, A, 300, 810)), norm, 0)
-    assert critic is v.critic and count == 0 and loss_mean == 0
+    assert count == 0 and loss_mean == 0
+    # what comes back is a snapshot of the critic (a pickled copy in the reference), not the live module
+    assert critic is not v.critic and type(critic) is type(v.critic)
+    v.synchronize()
+    assert torch.equal(critic.arena.data, v.critic.arena.data)
     for s in range(3):
         v.learn(indices=T(g[f"{tag}_idx"][s]), noise=T(g[f"{tag}_noise"][s]))
+        v.synchronize()
         loss = v.loss_ring[s % 5].item()
         np.testing.assert_allclose(loss, g[f"{tag}_loss"][s], rtol=2e-5)
         _check_module(v.critic, g, f"{tag}_s{s}_p_")
@@ -69,12 +79,13 @@ def test_v_learner_golden_trace(golden, dev, distl):
     np.testing.assert_allclose(v.loss_mean(), np.mean([0, 0, *g[f"{tag}_loss"]]), rtol=2e-5)   # Tracker(5) semantics
 
 
+@pytest.mark.parametrize("streams", [False, True])
 @pytest.mark.parametrize("distl", [False, True])
-def test_p_learner_golden_trace(golden, dev, distl):
+def test_p_learner_golden_trace(golden, dev, distl, streams):
     from pql_amd.algo.pql_p_learner import PQLPLearner
     from pql_amd.models.mlp import DistributionalDoubleQ, DoubleQ
     g = golden("learners"); tag = "pd" if distl else "p"; O, A = 8, 2
-    p = PQLPLearner((O,), A, make_cfg(distl))
+    p = PQLPLearner((O,), A, make_cfg(distl, streams=streams))
     p.actor.load_state_dict(_sd(dd.mlp_state(O, A, 11)))
     if distl:
         critic = DistributionalDoubleQ((O,), A, v_min=-10, v_max=10, num_atoms=51, device=dev).to(dev)
@@ -83,9 +94,10 @@ def test_p_learner_golden_trace(golden, dev, distl):
         critic = DoubleQ((O,), A).to(dev); critic.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 21)))
     norm = (T(g["learner_norm_mean"]).to(dev), T(g["learner_norm_var"]).to(dev), 1e-4)
     actor, _, count = p.update(critic, _fill(O, A, 300, 810)[0].to(dev), norm, 0)
-    assert actor is p.actor and count == 0 and (p.next_p, p.cur_capacity) == (300, 300)
+    assert actor is not p.actor and count == 0 and (p.next_p, p.cur_capacity) == (300, 300)
     for s in range(3):
         p.learn(indices=T(g[f"{tag}_idx"][s]))
+        p.synchronize()
         np.testing.assert_allclose(p.loss_ring[s % 5].item(), g[f"{tag}_loss"][s], rtol=2e-5)
         if not distl:
             _check_module(p.actor, g, f"p_s{s}_p_")
@@ -100,8 +112,9 @@ def test_learn_is_noop_before_first_update(dev):
     assert p.learn() == 0.01 and p.update_count == 0     # pql_p_learner.py:48, sleep_time default 0.01
 
 
+@pytest.mark.parametrize("streams", [False, True])
 @pytest.mark.parametrize("hidden", [None, [512, 512, 256]])
-def test_full_size_step_vs_oracle(dev, hidden):
+def test_full_size_step_vs_oracle(dev, hidden, streams):
     """cfg #2 shapes (obs 88, act 16, batch 8192), reference-default and BASELINE hidden sizes: two V steps and
     two P steps with injected samples vs the CPU oracle; losses at 1e-5 relative.  Parameters: rtol 1e-5 with
     atol 1e-5 = 2 % of one Adam step (lr 5e-4): Adam divides by sqrt(v), so an entry whose gradient is ~0 turns a
@@ -111,7 +124,7 @@ def test_full_size_step_vs_oracle(dev, hidden):
     from pql_amd.algo.pql_v_learner import PQLVLearner
     O, A, B, cap = 88, 16, 8192, 20000
     hid = tuple(hidden) if hidden else (512, 256, 128)
-    cfg = make_cfg(False, B=B, memory=cap, hidden=hidden)
+    cfg = make_cfg(False, B=B, memory=cap, hidden=hidden, streams=streams)
     v = PQLVLearner((O,), A, cfg); p = PQLPLearner((O,), A, cfg)
     cst = dd.doubleq_state(O, A, 1, 21, hid); ast = dd.mlp_state(O, A, 11, hid)
     v.critic.load_state_dict(_sd(cst)); v.critic_target.arena.data.copy_(v.critic.arena.data)
@@ -130,9 +143,11 @@ def test_full_size_step_vs_oracle(dev, hidden):
         idx = T(dd.integers((B,), 900 + s, cap - 100)); draw = T(dd.uniform((B, A), 950 + s, -2, 2))
         lv = vr.learn(idx=idx, draw=draw)
         v.learn(indices=idx, noise=draw)
+        v.synchronize()
         np.testing.assert_allclose(v.loss_ring[s % 5].item(), lv, rtol=1e-5)
         lp = pr.learn(idx=idx)
         p.learn(indices=idx)
+        p.synchronize()
         np.testing.assert_allclose(p.loss_ring[s % 5].item(), lp, rtol=1e-5, atol=1e-7)
     lay = v.critic.layout
     k = 0
@@ -147,6 +162,96 @@ def test_full_size_step_vs_oracle(dev, hidden):
         np.testing.assert_allclose(al.weight(p.actor.arena.data, 0, l).cpu().numpy(), pr.actor[2 * l].detach().numpy(),
                                    rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(lay.weight(v.critic_target.arena.data, 0, 0).cpu().numpy(), vr.t1[0].numpy(), rtol=1e-5, atol=1e-5)
+
+
+def _compare_nets(module, nets, rtol=1e-5, atol=1e-5):
+    lay = module.layout
+    for n, net in enumerate(nets):
+        for l in range(lay.n_layers):
+            np.testing.assert_allclose(lay.weight(module.arena.data, n, l).cpu().numpy(), net[2 * l].detach().numpy(),
+                                       rtol=rtol, atol=atol, err_msg=f"net {n} layer {l} weight")
+            np.testing.assert_allclose(lay.bias(module.arena.data, n, l).cpu().numpy(), net[2 * l + 1].detach().numpy(),
+                                       rtol=rtol, atol=atol, err_msg=f"net {n} layer {l} bias")
+
+
+def test_cfg4_pqld_shadowhand_shape_learner_steps_vs_oracle(dev):
+    """BASELINE configs[3] at learner level: PQL-D (DistributionalDoubleQ, 51 atoms, v in [-10, 10]) at ShadowHand shape
+    (obs 211, act 20), batch 8192 -- two V steps (C51 projection x2, min, BCE, backward, clip + AdamW + Polyak) and two P
+    steps (DPG through the expected value of the frozen categorical critic) in the measured mode (own streams) against
+    the CPU oracle on identical replay samples and noise.  Tolerances as in test_full_size_step_vs_oracle."""
+    from oracle import pql_ref_cpu as ref
+    from pql_amd.algo.pql_p_learner import PQLPLearner
+    from pql_amd.algo.pql_v_learner import PQLVLearner
+    O, A, B, cap, K = 211, 20, 8192, 20000, 51
+    cfg = make_cfg(True, B=B, memory=cap, streams=True, task="ShadowHand")
+    v = PQLVLearner((O,), A, cfg); p = PQLPLearner((O,), A, cfg)
+    assert v.critic.num_atoms == K and v.critic.layout.dims[0] == O + A
+    cst = dd.doubleq_state(O, A, K, 41); ast = dd.mlp_state(O, A, 43)
+    v.critic.load_state_dict(_sd(cst)); v.critic_target.arena.data.copy_(v.critic.arena.data)
+    p.actor.load_state_dict(_sd(ast))
+    rows = cap - 100
+    data = list(_fill(O, A, rows, 177))
+    data[2] = T(dd.uniform((rows, 1), 179, -2.0, 2.0))    # rewards wide enough to move mass across several atoms
+    data = tuple(data)
+    mean, var = T(dd.uniform((O,), 811, -0.5, 0.5)), T(dd.uniform((O,), 812, 0.5, 2.0))
+    hp = ref.HyperRef(batch_size=B, distl=True)
+    vr = ref.VLearnerRef(O, A, hp, cap, ref.params_from_state(cst, "net_q1.net."), ref.params_from_state(cst, "net_q2.net."))
+    pr = ref.PLearnerRef(O, A, hp, cap, ref.params_from_state(ast))
+    vr.update(ref.params_from_state(ast), data, (mean, var, 1e-4))
+    pr.update(vr.q1, vr.q2, data[0], (mean, var, 1e-4))
+    norm = (mean.to(dev), var.to(dev), 1e-4)
+    critic, _, _ = v.update(p.actor, tuple(t.to(dev) for t in data), norm, 0)
+    p.update(critic, data[0].to(dev), norm, 0)
+    for s in range(2):
+        idx = T(dd.integers((B,), 920 + s, rows)); draw = T(dd.uniform((B, A), 970 + s, -2, 2))
+        lv = vr.learn(idx=idx, draw=draw)
+        v.learn(indices=idx, noise=draw)
+        v.synchronize()
+        np.testing.assert_allclose(v.loss_ring[s % 5].item(), lv, rtol=2e-5)
+        lp = pr.learn(idx=idx)
+        p.learn(indices=idx)
+        p.synchronize()
+        np.testing.assert_allclose(p.loss_ring[s % 5].item(), lp, rtol=2e-5, atol=1e-6)
+    _compare_nets(v.critic, (vr.q1, vr.q2))
+    _compare_nets(v.critic_target, (vr.t1, vr.t2))
+    _compare_nets(p.actor, (pr.actor,))
+
+
+def test_cfg5_humanoid_nstep5_batch32768_v_step_vs_oracle(dev):
+    """BASELINE configs[4] at learner level: obs 108 / act 21, n-step 5 (gamma^5 in the TD target), batch 32768 -- one V step
+    and one P step against the CPU oracle (own streams)."""
+    from oracle import pql_ref_cpu as ref
+    from pql_amd.algo.pql_p_learner import PQLPLearner
+    from pql_amd.algo.pql_v_learner import PQLVLearner
+    O, A, B, cap = 108, 21, 32768, 50000
+    cfg = make_cfg(False, B=B, memory=cap, nstep=5, streams=True, task="Humanoid")
+    v = PQLVLearner((O,), A, cfg); p = PQLPLearner((O,), A, cfg)
+    cst = dd.doubleq_state(O, A, 1, 51); ast = dd.mlp_state(O, A, 53)
+    v.critic.load_state_dict(_sd(cst)); v.critic_target.arena.data.copy_(v.critic.arena.data)
+    p.actor.load_state_dict(_sd(ast))
+    rows = cap - 10
+    data = _fill(O, A, rows, 277)
+    mean, var = T(dd.uniform((O,), 821, -0.5, 0.5)), T(dd.uniform((O,), 822, 0.5, 2.0))
+    hp = ref.HyperRef(batch_size=B, nstep=5)
+    vr = ref.VLearnerRef(O, A, hp, cap, ref.params_from_state(cst, "net_q1.net."), ref.params_from_state(cst, "net_q2.net."))
+    pr = ref.PLearnerRef(O, A, hp, cap, ref.params_from_state(ast))
+    vr.update(ref.params_from_state(ast), data, (mean, var, 1e-4))
+    pr.update(vr.q1, vr.q2, data[0], (mean, var, 1e-4))
+    norm = (mean.to(dev), var.to(dev), 1e-4)
+    critic, _, _ = v.update(p.actor, tuple(t.to(dev) for t in data), norm, 0)
+    p.update(critic, data[0].to(dev), norm, 0)
+    idx = T(dd.integers((B,), 930, rows)); draw = T(dd.uniform((B, A), 980, -2, 2))
+    lv = vr.learn(idx=idx, draw=draw)
+    v.learn(indices=idx, noise=draw)
+    v.synchronize()
+    np.testing.assert_allclose(v.loss_ring[0].item(), lv, rtol=1e-5)
+    lp = pr.learn(idx=idx)
+    p.learn(indices=idx)
+    p.synchronize()
+    np.testing.assert_allclose(p.loss_ring[0].item(), lp, rtol=1e-5, atol=1e-7)
+    _compare_nets(v.critic, (vr.q1, vr.q2))
+    _compare_nets(v.critic_target, (vr.t1, vr.t2))
+    _compare_nets(p.actor, (pr.actor,))
 
 
 def test_graph_replay_matches_eager(dev):
