@@ -72,7 +72,8 @@ class PQLPLearner:
         # start()/update() hand out double-buffered snapshots of the actor (a pickled copy in the reference)
         self._pub = H.ArenaPublisher(self.actor)
         self._lock = threading.RLock()   # learn() / update() are FIFO like calls on a Ray actor
-        self.gen = None                  # private RNG (use_private_rng)
+        self.gen = torch.Generator(device=self.device)   # own generator: see PQLVLearner.__init__
+        self.gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
         self._ws = None
         self._graph = None
         self._graph_post = None
@@ -95,8 +96,7 @@ class PQLPLearner:
         return self._pub.publish()
 
     def use_private_rng(self, seed):
-        """Own device generator for a free-running learner thread (see PQLVLearner.use_private_rng)."""
-        self.gen = torch.Generator(device=self.device)
+        """Re-seed this learner's generator."""
         self.gen.manual_seed(int(seed))
         self._graph = None
 

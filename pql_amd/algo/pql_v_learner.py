@@ -234,7 +234,12 @@ class PQLVLearner:
         # caller holds are those of the hand-off, not of whenever it gets round to using them
         self._pub = H.ArenaPublisher(self.critic)
         self._lock = threading.RLock()   # learn() / update() are FIFO like calls on a Ray actor
-        self.gen = None                  # private RNG (use_private_rng): one generator per free-running learner thread
+        # Own device generator, like the reference's learner PROCESS has its own default generator.  Not a
+        # nicety: every hipGraph that draws from a generator is handed its Philox offset through ONE device word per
+        # generator, refreshed on the replaying stream -- two learners replaying graphs on two streams off the shared
+        # default generator overwrite each other's offset (measured: different sample indices from run to run).
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))   # derived from the driver's seed (CPU generator)
         self._ws = None
         self._graph = None
         self._graph_post = None
@@ -253,10 +258,7 @@ class PQLVLearner:
         return self._pub.publish()
 
     def use_private_rng(self, seed):
-        """Give this learner its own device generator (the reference's learners are separate processes with their own
-        default generators).  Needed when learners free-run in threads: two threads must not interleave draws -- or a
-        graph capture -- on the shared default generator."""
-        self.gen = torch.Generator(device=self.device)
+        """Re-seed this learner's generator."""
         self.gen.manual_seed(int(seed))
         self._graph = None
 

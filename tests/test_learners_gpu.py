@@ -266,7 +266,7 @@ def test_graph_replay_matches_eager(dev):
         v = PQLVLearner((O,), A, make_cfg(False, B=B, memory=cap, graph=graph))
         v.critic.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 21))); v.critic_target.arena.data.copy_(v.critic.arena.data)
         v.update(actor, tuple(t.to(dev) for t in _fill(O, A, cap, 5)), None, 0)
-        torch.manual_seed(1234)
+        v.use_private_rng(1234)
         for _ in range(4):
             v.learn()
         torch.cuda.synchronize()
@@ -372,7 +372,7 @@ def _dp_rank(rank, world, port, ret):
                 v.learn(indices=T(g["v_idx"][0][sl]), noise=T(g["v_noise"][0][sl]))
                 outs["injected"] = dd.summarize(v.critic.layout.weight(v.critic.arena.data, 0, 1).cpu().numpy())
             else:           # graph mode: two captured graphs around the eager all-reduce; replicas must stay identical
-                torch.manual_seed(99)
+                v.use_private_rng(99)
                 for _ in range(3):
                     v.learn()
                 torch.cuda.synchronize()
