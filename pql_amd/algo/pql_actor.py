@@ -65,6 +65,13 @@ class PQLActor:
         self.obs_rms = RunningMeanStd(shape=self.obs_dim, device=dev) if algo.obs_norm else None
         self.n_step_buffer = NStepReplay(self.obs_dim, self.action_dim, n, algo.nstep, device=dev)
         self.noise_scheduler = self._make_scheduler(algo.noise)
+        # own device generator for the exploration draws, as the reference's actor process has its own: the default generator
+        # is switched into capture mode whenever ANY hipGraph is being captured (a learner thread re-capturing its step),
+        # and an eager draw from it at that moment raises
+        self.gen = None
+        if self.sim_device.type == "cuda":
+            self.gen = torch.Generator(device=self.sim_device)
+            self.gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
         self._slabs = {}   # (N, T, .) trajectory slabs, allocated once per horizon length and reused
         # n-step output blocks handed to the learners: OUT_BLOCKS per block size, each with a lease so that the rollout
         # stream re-uses one only after the learners' streams have inserted it (pql_amd.utils.handoff)
@@ -101,9 +108,9 @@ class PQLActor:
         noise = self.cfg.algo.noise
         if noise.type == "mixed":
             return add_mixed_normal_noise(act, std_min=noise.std_min, std_max=noise.std_max, out_bounds=[-1., 1.],
-                                          env_offset=self.env_offset, total_envs=self.total_envs)
+                                          env_offset=self.env_offset, total_envs=self.total_envs, generator=self.gen)
         if noise.type == "fixed":
-            return add_normal_noise(act, std=self.get_noise_std(), out_bounds=[-1., 1.])
+            return add_normal_noise(act, std=self.get_noise_std(), out_bounds=[-1., 1.], generator=self.gen)
         raise NotImplementedError(noise.type)
 
     @torch.no_grad()
@@ -165,7 +172,7 @@ class PQLActor:
             if self.obs_rms is not None:
                 self.obs_rms.update(obs)
             if random:   # warm-up: U(-1, 1) actions
-                action = torch.rand((n, self.action_dim), device=self.sim_device).mul_(2.0).sub_(1.0)
+                action = torch.rand((n, self.action_dim), device=self.sim_device, generator=self.gen).mul_(2.0).sub_(1.0)
             else:
                 action = self.get_actions(obs, sample=True)
             next_obs, reward, done, info = env.step(action)

@@ -72,6 +72,7 @@ class PQLPLearner:
         # start()/update() hand out double-buffered snapshots of the actor (a pickled copy in the reference)
         self._pub = H.ArenaPublisher(self.actor)
         self._lock = threading.RLock()   # learn() / update() are FIFO like calls on a Ray actor
+        self._capture_stream = torch.cuda.Stream(self.device)   # torch's default capture stream is shared by every graph
         self.gen = torch.Generator(device=self.device)   # own generator: see PQLVLearner.__init__
         self.gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
         self._ws = None
@@ -203,7 +204,8 @@ class PQLPLearner:
             elif self.use_graph:
                 key = (B, self.cur_capacity, id(self.critic), self.normalize_tuple is None)
                 if self._graph is None or self._graph_key != key:
-                    self._capture(ws, key)
+                    with H.CAPTURE_LOCK:
+                        self._capture(ws, key)
                 self._graph.replay()
                 if self._graph_post is not None:
                     self._allreduce_grads(ws)
@@ -247,13 +249,13 @@ class PQLPLearner:
         # PQL_DP_GRAPH_COLLECTIVE=1 (opt-in, RCCL only, rehearsed with a 1-rank group only): capture the all-reduce inside
         # ONE graph instead of splitting the step around an eager collective
         if not self.dp or graph_collective_enabled(self.pg):
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
                 self._draw_and_step(ws)
         else:
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
                 self._draw_and_step(ws, upto_backward=True)
             g_post = self._new_graph()
-            with torch.cuda.graph(g_post, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g_post, stream=self._capture_stream, capture_error_mode="thread_local"):
                 self._step_post(ws)
         self._set_rng_state(rng)
         self._graph, self._graph_post, self._graph_key = g, g_post, key

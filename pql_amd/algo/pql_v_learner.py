@@ -234,6 +234,7 @@ class PQLVLearner:
         # caller holds are those of the hand-off, not of whenever it gets round to using them
         self._pub = H.ArenaPublisher(self.critic)
         self._lock = threading.RLock()   # learn() / update() are FIFO like calls on a Ray actor
+        self._capture_stream = torch.cuda.Stream(self.device)   # torch's default capture stream is shared by every graph
         # Own device generator, like the reference's learner PROCESS has its own default generator.  Not a
         # nicety: every hipGraph that draws from a generator is handed its Philox offset through ONE device word per
         # generator, refreshed on the replaying stream -- two learners replaying graphs on two streams off the shared
@@ -400,7 +401,8 @@ class PQLVLearner:
             elif self.use_graph:
                 key = (B, self.memory.cur_capacity, id(self.actor), self.normalize_tuple is None)
                 if self._graph is None or self._graph_key != key:
-                    self._capture(ws, key)
+                    with H.CAPTURE_LOCK:
+                        self._capture(ws, key)
                 self._graph.replay()
                 if self._graph_post is not None:   # data parallel: the collective stays outside the graphs
                     self._allreduce_grads(ws)
@@ -431,13 +433,13 @@ class PQLVLearner:
         # PQL_DP_GRAPH_COLLECTIVE=1 (opt-in, RCCL only, rehearsed with a 1-rank group only): capture the all-reduce inside
         # ONE graph instead of splitting the step around an eager collective
         if not self.dp or graph_collective_enabled(self.pg):
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
                 self._draw_and_step(ws)
         else:   # two graphs around the RCCL all-reduce (kept eager: no collective is ever captured)
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
                 self._draw_and_step(ws, upto_backward=True)
             g_post = self._new_graph()
-            with torch.cuda.graph(g_post, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g_post, stream=self._capture_stream, capture_error_mode="thread_local"):
                 self._step_post(ws)
         self._restore(snap)  # capture does not execute, but keep state exactly as before
         self._graph, self._graph_post, self._graph_key = g, g_post, key

@@ -27,6 +27,7 @@ import threading
 import torch
 
 LOCK = threading.RLock()   # lease bookkeeping + the enqueue of the copy it guards are one atomic step between threads
+CAPTURE_LOCK = threading.Lock()   # one hipGraph capture at a time per process (learner threads capture lazily)
 # Rehearsal switch (tests / one-GPU boxes): route same-device hand-offs through the copy streams and landing blocks as
 # if the learners sat on another GPU, so the two-GPU code path runs on one card.
 FORCE_SHIP = os.environ.get("PQL_FORCE_SHIP", "0") == "1"

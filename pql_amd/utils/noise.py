@@ -2,23 +2,24 @@
 import torch
 
 
-def _draw(shape, dtype, device, std):
+def _draw(shape, dtype, device, std, generator=None):
     # torch.normal(zeros, std_tensor) consumes the generator as normal_(0,1) then scales (Appendix B of SURVEY.md)
-    return torch.empty(shape, dtype=dtype, device=device).normal_() * std
+    return torch.empty(shape, dtype=dtype, device=device).normal_(generator=generator) * std
 
 
 _STD_CACHE = {}
 
 
-def add_normal_noise(x, std, noise_bounds=None, out_bounds=None):
-    noise = _draw(x.shape, x.dtype, x.device, std)
+def add_normal_noise(x, std, noise_bounds=None, out_bounds=None, generator=None):
+    noise = _draw(x.shape, x.dtype, x.device, std, generator)
     if noise_bounds is not None:
         noise = noise.clamp(noise_bounds[0], noise_bounds[1])
     out = x + noise
     return out if out_bounds is None else out.clamp(out_bounds[0], out_bounds[1])
 
 
-def add_mixed_normal_noise(x, std_max, std_min, noise_bounds=None, out_bounds=None, env_offset=0, total_envs=None):
+def add_mixed_normal_noise(x, std_max, std_min, noise_bounds=None, out_bounds=None, env_offset=0, total_envs=None,
+                           generator=None):
     """Per-env sigma = linspace(std_min, std_max, N)[env].  env_offset/total_envs let a data-parallel
     rank index the GLOBAL env axis."""
     n = x.shape[0] if total_envs is None else total_envs
@@ -27,7 +28,7 @@ def add_mixed_normal_noise(x, std_max, std_min, noise_bounds=None, out_bounds=No
     if std is None:   # built on the host like the reference (same fp32 values), uploaded ONCE: no per-step H2D sync
         std = torch.linspace(std_min, std_max, n)[env_offset: env_offset + x.shape[0]].to(x.device).unsqueeze(-1)
         _STD_CACHE[key] = std
-    noise = _draw(x.shape, x.dtype, x.device, 1.0) * std
+    noise = _draw(x.shape, x.dtype, x.device, 1.0, generator) * std
     if noise_bounds is not None:
         noise = noise.clamp(noise_bounds[0], noise_bounds[1])
     out = x + noise

@@ -192,3 +192,37 @@ def test_train_pql_free_running_with_ratio_controller():
     assert 4.0 < v_per < 12.0, out
     assert 1.5 < out["critic_updates"] / out["actor_updates"] < 2.7, out
     assert p_per > 1.5, out
+
+
+def _run_bench(*flags, timeout=600):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--num-envs", "256", "--batch", "1024", "--replay", "20000",
+                        "--steps", "16", "--warmup", "8", "--repeat", "2", "--no-cpu-baseline", *flags],
+                       env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_launches_its_own_ranks_for_data_parallel():
+    """`python bench.py --gpus 2` from a bare shell (no torchrun, no WORLD_SIZE) must start two ranks itself.  One card here, so
+    the rehearsal form: gloo + --share-gpu, and the line has to say so instead of passing for a two-GPU RCCL run."""
+    line = _run_bench("--gpus", "2", "--backend", "gloo", "--share-gpu")
+    cfg = line["config"]
+    assert cfg["ranks"] == 2 and cfg["backend"] == "gloo" and cfg["share_gpu"] is True and cfg["parallelism"] == "dp2"
+    assert line["n_gpus"] == 1 and "gloo grad all-reduce" in cfg["workload"]
+    assert line["value"] > 0 and line["steps"] == 16 and line["scaling"] == "weak"
+
+
+def test_bench_split2_layout_rehearsed_on_one_card():
+    """BASELINE configs[2] entry: simulator on GPU 0, learners on GPU 1, copy-stream hand-offs.  With --share-gpu both are
+    cuda:0 and every hand-off still goes through the Shipper path."""
+    line = _run_bench("--gpus", "2", "--layout", "split2", "--share-gpu")
+    cfg = line["config"]
+    assert cfg["layout"] == "split2" and cfg["ranks"] == 1 and cfg["share_gpu"] is True and line["n_gpus"] == 1
+    assert "functional split" in cfg["workload"] and line["value"] > 0
+    assert line["roofline"]["frac"] > 0 and line["roofline_gather"]["frac"] > 0
