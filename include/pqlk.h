@@ -194,12 +194,25 @@ int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const float* x, 
                       const float* dx_tanh_of, int64_t ld_tanh,
                       float* ws, int64_t ws_floats, pqlk_stream_t stream);
 
+/* Same backward, with clip_grad_norm_'s first half folded into its last pass (pql_v_learner.py:128): the kernel that sums
+ * the split slabs into `grads` also leaves the per-block partials of sum(g^2) in sumsq_part[0, pqlk_sumsq_parts(n))
+ * (n = pqlk_mlp_param_floats) and increments the optimiser's device step counter.  Follow with
+ * pqlk_adamw_polyak_fused(prenorm = 1).  Bit-identical to pqlk_mlp_backward + pqlk_clip_adamw_polyak*.  Not for data
+ * parallel, where the gradient all-reduce sits between backward and the norm. */
+int pqlk_mlp_backward_norm(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                           const float* acts, const float* dy, float* grads, int32_t splits,
+                           float* dx, int64_t ld_dx, int32_t dx_col0, int32_t dx_cols,
+                           const float* dx_tanh_of, int64_t ld_tanh,
+                           float* ws, int64_t ws_floats, float* sumsq_part, int32_t* step_dev, pqlk_stream_t stream);
+int32_t pqlk_sumsq_parts(int64_t n);
+
 /* ------------------------------------------------------------------------------------------------
  * Losses.  Each writes dy (2, B, ld) for pqlk_mlp_backward and one scalar loss (device), via per-block
  * partials in `scratch` (>= 1024 floats) reduced in fixed order.  The scalar lands in
  * loss_out[slot_dev[0] % ring_len] when slot_dev != NULL (a device int32 counter, normally the optimiser's
  * step counter: gives a graph-replay-safe ring of the last `ring_len` losses, replacing the reference's
- * per-step `.item()` host sync, pql_v_learner.py:111), else in loss_out[0].
+ * per-step `.item()` host sync, pql_v_learner.py:111), else in loss_out[0].  loss_out = NULL leaves the per-block
+ * partials in scratch[0, pqlk_loss_parts(b, k)) for pqlk_adamw_polyak_fused to fold (one launch less).
  * ---------------------------------------------------------------------------------------------- */
 
 /* TD target + twin MSE (pql_v_learner.py:104-108): y = r + (1-d) * gamma_n * min(qt1, qt2);
@@ -251,6 +264,22 @@ int pqlk_clip_adamw_polyak_pack(const PqlMlpDesc* d, float* p, float* g, float* 
                                 float* packed_p, float* packed_t, float grad_scale, float max_norm, float lr, float b1,
                                 float b2, float eps, float wd, float tau, int32_t* step_dev, float* gnorm_out,
                                 float* scratch, pqlk_stream_t stream);
+
+/* The optimiser launch of a fused learner step (pql_v_learner.py:124-133 + :109-111, pql_p_learner.py:87-96): the same
+ * update as pqlk_clip_adamw_polyak_pack (packed_p may be NULL: nothing to re-pack), plus
+ *   prenorm != 0 : `scratch` already holds the squared-norm partials and step_dev is already incremented (both left by
+ *                  pqlk_mlp_backward_norm), so no separate norm launch;
+ *   loss_part    : per-block loss partials left in a loss kernel's scratch (pqlk_td_mse_loss / pqlk_c51_bce_loss /
+ *                  pqlk_dpg_loss called with loss_out = NULL; count = pqlk_loss_parts(b, k)): block 0 folds them, times
+ *                  loss_scale (1/B, 1/(B K), -1/B), into loss_ring[(t - 1) % ring_len], t = the incremented step --
+ *                  the slot and the bits the stand-alone fold writes.  NULL = no fold. */
+int pqlk_adamw_polyak_fused(const PqlMlpDesc* d, float* p, float* g, float* m, float* v, float* target,
+                            float* packed_p, float* packed_t, float grad_scale, float max_norm, float lr, float b1,
+                            float b2, float eps, float wd, float tau, int32_t* step_dev, float* gnorm_out,
+                            float* scratch, int32_t prenorm, const float* loss_part, int32_t loss_parts,
+                            float loss_scale, float* loss_ring, int32_t ring_len, pqlk_stream_t stream);
+/* Number of per-block partials a loss entry point leaves in `scratch` (k = atoms; 1 for scalar heads). */
+int32_t pqlk_loss_parts(int64_t b, int32_t k);
 
 /* soft_update alone (torch_util.py:9-12): target = cur*tau + target*(1-tau). */
 int pqlk_polyak(float* target, const float* cur, int64_t n, float tau, pqlk_stream_t stream);

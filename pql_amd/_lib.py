@@ -51,12 +51,18 @@ PROTOTYPES = {
     "pqlk_mlp_forward": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I32, _P, _I64, _I64, _I32, _P, _F, _F, _P, _P, _I64, _P]),
     "pqlk_mlp_backward": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _P, _I64,
                                     _P, _I64, _P]),
+    "pqlk_mlp_backward_norm": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _P, _I64,
+                                         _P, _I64, _P, _P, _P]),
+    "pqlk_sumsq_parts": (_I32, [_I64]),
     "pqlk_td_mse_loss": (C.c_int, [_P, _P, _I64, _P, _P, _F, _I64, _P, _P, _P, _I32, _P, _P]),
     "pqlk_c51_bce_loss": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _F, _F, _F, _I64, _P, _P, _P, _I32, _P, _P, _P]),
     "pqlk_c51_project": (C.c_int, [_P, _P, _P, _P, _F, _F, _F, _I32, _I64, _P, _P]),
     "pqlk_dpg_loss": (C.c_int, [_P, _I64, _I32, _P, _I64, _P, _P, _P, _I32, _P, _P]),
     "pqlk_clip_adamw_polyak": (C.c_int, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
     "pqlk_clip_adamw_polyak_pack": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
+    "pqlk_adamw_polyak_fused": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _F, _F, _F, _F, _P, _P, _P,
+                                          _I32, _P, _I32, _F, _P, _I32, _P]),
+    "pqlk_loss_parts": (_I32, [_I64, _I32]),
     "pqlk_polyak": (C.c_int, [_P, _P, _I64, _F, _P]),
     "pqlk_sg_head_forward": (C.c_int, [_P, _I64, _P, _I64, _I32, _P, _I64, _P, _P]),
     "pqlk_sg_head_backward": (C.c_int, [_P, _I64, _P, _P, _I64, _P, _I64, _P, _F, _I64, _I32, _P, _P]),

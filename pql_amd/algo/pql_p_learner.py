@@ -20,7 +20,7 @@ import torch
 
 from pql_amd import _lib as L
 from pql_amd.algo.pql_v_learner import (LOSS_RING, LaggedLoss, _AdamState, _cfg_get, adopt_arena, allreduce_sum, apply_optimizer,
-                                        graph_collective_enabled, pump, resident_norm)
+                                        apply_optimizer_fused, f32_recip, graph_collective_enabled, pump, resident_norm)
 from pql_amd.models import model_name_to_path
 from pql_amd.models.mlp import PackedWeights, default_splits, mlp_forward_raw, output_view
 from pql_amd.replay.simple_replay import RecordRing, _obs_width, ring_plan
@@ -50,6 +50,7 @@ class PQLPLearner:
             raise NotImplementedError("W&B artifact download is out of scope (no network); load a local state_dict instead")
         self.opt = _AdamState(self.actor.arena.data)
         self._fused = bool(_cfg_get(algo, "fused", True))
+        self._fused_tail = not self.dp and bool(_cfg_get(algo, "fused_tail", True))
         self.pk_actor = PackedWeights(self.actor.layout, self.device) if self._fused else None
         self.pk_critic = None
         self.critic = None
@@ -160,15 +161,22 @@ class PQLPLearner:
         q = output_view(cl, ws["acts_c"], B)
         K = int(getattr(self.critic, "num_atoms", 1))
         z = getattr(self.critic, "z_atoms", None) if K > 1 else None
-        L.check(L.lib.pqlk_dpg_loss(L.ptr(q), cl.ld_out, K, L.ptr(z), B, L.ptr(ws["dy_c"]), L.ptr(self.loss_ring),
+        tail = self._fused_tail   # see PQLVLearner._step_kernels
+        L.check(L.lib.pqlk_dpg_loss(L.ptr(q), cl.ld_out, K, L.ptr(z), B, L.ptr(ws["dy_c"]), None if tail else L.ptr(self.loss_ring),
                                     L.ptr(self.opt.step), LOSS_RING, L.ptr(ws["scratch"]), st))
         a_out = output_view(al, ws["acts_a"], B)  # (1, B, ld_a): tanh output, for the tanh' chain
         L.check(L.lib.pqlk_mlp_backward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
                                         L.ptr(ws["acts_c"]), L.ptr(ws["dy_c"]), None, 1, L.ptr(ws["dz_a"]), ws["ld_a"], O, A,
                                         L.ptr(a_out), ws["ld_a"], L.ptr(ws["bwd_c"]), ws["bwd_c"].numel(), st))
-        L.check(L.lib.pqlk_mlp_backward(C.byref(al.desc), L.ptr(self.actor.arena.data), L.ptr(ws["x_obs"]), ws["ld_o"], B,
-                                        L.ptr(ws["acts_a"]), L.ptr(ws["dz_a"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0, 0,
-                                        None, 0, L.ptr(ws["bwd_a"]), ws["bwd_a"].numel(), st))
+        if tail:
+            L.check(L.lib.pqlk_mlp_backward_norm(C.byref(al.desc), L.ptr(self.actor.arena.data), L.ptr(ws["x_obs"]), ws["ld_o"], B,
+                                                 L.ptr(ws["acts_a"]), L.ptr(ws["dz_a"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0,
+                                                 0, None, 0, L.ptr(ws["bwd_a"]), ws["bwd_a"].numel(), L.ptr(self.opt.scratch),
+                                                 L.ptr(self.opt.step), st))
+        else:
+            L.check(L.lib.pqlk_mlp_backward(C.byref(al.desc), L.ptr(self.actor.arena.data), L.ptr(ws["x_obs"]), ws["ld_o"], B,
+                                            L.ptr(ws["acts_a"]), L.ptr(ws["dz_a"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0, 0,
+                                            None, 0, L.ptr(ws["bwd_a"]), ws["bwd_a"].numel(), st))
         if upto_backward:
             return
         self._allreduce_grads(ws)
@@ -180,11 +188,17 @@ class PQLPLearner:
 
     def _step_post(self, ws):
         algo = self.cfg.algo
+        if self._fused_tail:
+            K = int(getattr(self.critic, "num_atoms", 1))
+            apply_optimizer_fused(self.actor.layout, self.actor.arena.data, ws["grads"], self.opt, None, algo.actor_lr,
+                                  algo.max_grad_norm, 0.0, self.pk_actor, None, ws["scratch"], L.lib.pqlk_loss_parts(ws["B"], K),
+                                  f32_recip(ws["B"], sign=-1.0), self.loss_ring, self.device)
+            return
         apply_optimizer(self.actor.arena.data, ws["grads"], self.opt, None, algo.actor_lr, algo.max_grad_norm, 0.0,
                         1.0 / self.world, self.device, layout=self.actor.layout, packed=self.pk_actor)
 
     def _draw_and_step(self, ws, upto_backward=False):
-        ws["idx"].copy_(torch.randint(self.cur_capacity, size=(ws["B"],), device=self.device, generator=self.gen))  # the only draw (:49)
+        torch.randint(self.cur_capacity, (ws["B"],), generator=self.gen, out=ws["idx"])  # the only draw (:49), no copy launch
         self._step_kernels(ws, ws["idx"], upto_backward)
 
     @torch.no_grad()

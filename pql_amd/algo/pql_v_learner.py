@@ -73,6 +73,29 @@ def apply_optimizer(arena, grads, st: _AdamState, target, lr, max_grad_norm, tau
                                          L.ptr(st.scratch), L.stream(device)))
 
 
+def apply_optimizer_fused(layout, arena, grads, st: _AdamState, target, lr, max_grad_norm, tau, packed, packed_target,
+                          loss_part, loss_parts, loss_scale, loss_ring, device):
+    """Tail of a fused single-GPU learner step: AdamW (+ Polyak + re-pack) whose launch also folds the loss partials into
+    the loss ring; the squared-norm partials and the step increment were left in `st.scratch` / `st.step` by
+    `pqlk_mlp_backward_norm`.  Same bits as apply_optimizer + the stand-alone folds, two launches fewer."""
+    mn = float(max_grad_norm) if max_grad_norm is not None else 0.0
+    pk = packed.tensor if packed is not None else None
+    pt = packed_target.tensor if packed_target is not None else None
+    L.check(L.lib.pqlk_adamw_polyak_fused(C.byref(layout.desc), L.ptr(arena), L.ptr(grads), L.ptr(st.m), L.ptr(st.v), L.ptr(target),
+                                          L.ptr(pk), L.ptr(pt), 1.0, mn, float(lr), 0.9, 0.999, 1e-8, 1e-2, float(tau),
+                                          L.ptr(st.step), L.ptr(st.gnorm), L.ptr(st.scratch), 1, L.ptr(loss_part), int(loss_parts),
+                                          float(loss_scale), L.ptr(loss_ring), LOSS_RING, L.stream(device)))
+
+
+def f32_recip(*factors, sign=1.0):
+    """sign / (f0 * f1 ...) evaluated in fp32, like the kernels' `1.0f / ((float)b * (float)k)`."""
+    import numpy as np
+    d = np.float32(1.0)
+    for f in factors:
+        d = np.float32(d * np.float32(f))
+    return float(np.float32(sign) / d)
+
+
 def allreduce_sum(t, pg):
     """Sum-all-reduce of the flat gradient arena.  RCCL ("nccl") reduces in place on the device over xGMI; the
     gloo rehearsal path (CPU tests / one-GPU dry runs) stages through host memory."""
@@ -216,6 +239,7 @@ class PQLVLearner:
         self.pk_target = PackedWeights(self.critic.layout, self.device) if fused else None
         self.pk_actor = None
         self._fused = fused
+        self._fused_tail = not self.dp and bool(_cfg_get(algo, "fused_tail", True))
         self.actor = None
         self.memory = ReplayBuffer(capacity=int(algo.memory_size), obs_dim=self.obs_dim, action_dim=self.action_dim,
                                    device=self.device)
@@ -342,18 +366,28 @@ class PQLVLearner:
         q = output_view(cl, ws["acts_c"], B)
         qt = output_view(cl, ws["acts_t"], B)
         gamma_n = float(algo.gamma) ** int(algo.nstep)
+        # single GPU: the loss fold and the gradient-norm pass ride in launches that exist anyway (backward's slab
+        # reduction, the optimiser); data parallel keeps them apart because the all-reduce sits in between
+        tail = self._fused_tail
+        loss_out = None if tail else L.ptr(self.loss_ring)
         if algo.distl:
             L.check(L.lib.pqlk_c51_bce_loss(L.ptr(q), L.ptr(qt), cl.ld_out, int(algo.num_atoms), L.ptr(ws["rew"]),
                                             L.ptr(ws["done"]), L.ptr(self.critic.z_atoms), gamma_n, float(algo.v_min),
-                                            float(algo.v_max), B, L.ptr(ws["dy"]), L.ptr(self.loss_ring), L.ptr(self.opt.step),
+                                            float(algo.v_max), B, L.ptr(ws["dy"]), loss_out, L.ptr(self.opt.step),
                                             LOSS_RING, None, L.ptr(ws["scratch"]), st))
         else:
             L.check(L.lib.pqlk_td_mse_loss(L.ptr(q), L.ptr(qt), cl.ld_out, L.ptr(ws["rew"]), L.ptr(ws["done"]), gamma_n, B,
-                                           L.ptr(ws["dy"]), L.ptr(self.loss_ring), L.ptr(self.opt.step), LOSS_RING,
+                                           L.ptr(ws["dy"]), loss_out, L.ptr(self.opt.step), LOSS_RING,
                                            L.ptr(ws["scratch"]), st))
-        L.check(L.lib.pqlk_mlp_backward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
-                                        L.ptr(ws["acts_c"]), L.ptr(ws["dy"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0, 0,
-                                        None, 0, L.ptr(ws["bwd"]), ws["bwd"].numel(), st))
+        if tail:
+            L.check(L.lib.pqlk_mlp_backward_norm(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
+                                                 L.ptr(ws["acts_c"]), L.ptr(ws["dy"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0,
+                                                 0, None, 0, L.ptr(ws["bwd"]), ws["bwd"].numel(), L.ptr(self.opt.scratch),
+                                                 L.ptr(self.opt.step), st))
+        else:
+            L.check(L.lib.pqlk_mlp_backward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
+                                            L.ptr(ws["acts_c"]), L.ptr(ws["dy"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0, 0,
+                                            None, 0, L.ptr(ws["bwd"]), ws["bwd"].numel(), st))
         if upto_backward:
             return
         self._allreduce_grads(ws)
@@ -365,6 +399,13 @@ class PQLVLearner:
 
     def _step_post(self, ws):
         algo, dev = self.cfg.algo, self.device
+        if self._fused_tail:
+            K = int(algo.num_atoms) if algo.distl else 1
+            apply_optimizer_fused(self.critic.layout, self.critic.arena.data, ws["grads"], self.opt, self.critic_target.arena.data,
+                                  algo.critic_lr, algo.max_grad_norm, algo.tau, self.pk_critic, self.pk_target, ws["scratch"],
+                                  L.lib.pqlk_loss_parts(ws["B"], K), f32_recip(ws["B"], K) if K > 1 else f32_recip(ws["B"]),
+                                  self.loss_ring, dev)
+            return
         # optimiser + Polyak + refresh of the fragment-ordered weight copies (critic and target) in one launch pair
         apply_optimizer(self.critic.arena.data, ws["grads"], self.opt, self.critic_target.arena.data, algo.critic_lr,
                         algo.max_grad_norm, algo.tau, 1.0 / self.world, dev, layout=self.critic.layout,
@@ -374,7 +415,7 @@ class PQLVLearner:
         B = ws["B"]
         # RNG consumption order of the reference: one randint(cur_capacity,(B,)) then one
         # N(0,1) draw of shape (B, A) on the learner's device generator.
-        ws["idx"].copy_(torch.randint(self.memory.cur_capacity, size=(B,), device=self.device, generator=self.gen))
+        torch.randint(self.memory.cur_capacity, (B,), generator=self.gen, out=ws["idx"])   # straight into the workspace: no copy launch
         ws["draw"].normal_(generator=self.gen)
         self._step_kernels(ws, ws["idx"], ws["draw"], upto_backward)
 
@@ -392,7 +433,7 @@ class PQLVLearner:
                 if indices is not None:   # injected draws arrive on the caller's stream (or from the host)
                     self._inject(ws["idx"], indices, home)
                 else:
-                    ws["idx"].copy_(torch.randint(self.memory.cur_capacity, size=(B,), device=self.device, generator=self.gen))
+                    torch.randint(self.memory.cur_capacity, (B,), generator=self.gen, out=ws["idx"])
                 if noise is not None:
                     self._inject(ws["draw"], noise, home)
                 else:

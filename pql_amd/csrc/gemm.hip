@@ -578,9 +578,15 @@ static int64_t max_hidden_ld(const PqlMlpDesc* d) {
   return m;
 }
 
+static int64_t head_part_floats(const PqlMlpDesc* d, int64_t b) {   // room for k_skinny_bwd's per-block partials
+  const int L = d->n_layers;
+  const int64_t hf = (int64_t)d->dims[L] * pqlk_ld(d->dims[L - 1]) + pqlk_ld(d->dims[L]);
+  return (int64_t)skinny_bwd_blocks(b) * d->n_nets * hf;
+}
+
 extern "C" int64_t pqlk_mlp_bwd_ws_floats(const PqlMlpDesc* d, int64_t b, int32_t splits) {
   if (desc_ok(d) || b <= 0 || splits < 1) return 0;
-  return 2 * (int64_t)d->n_nets * b * max_hidden_ld(d) + (int64_t)splits * pqlk_mlp_param_floats(d);
+  return 2 * (int64_t)d->n_nets * b * max_hidden_ld(d) + (int64_t)splits * pqlk_mlp_param_floats(d) + head_part_floats(d, b);
 }
 
 // ================================================================================================
@@ -788,24 +794,68 @@ extern "C" int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// sum the split slabs in fixed order -> gradient arena (deterministic)
-__global__ __launch_bounds__(256) void k_reduce_slabs(const float* __restrict__ slabs, int splits, long long n,
-                                                      float* __restrict__ out) {
-  const long long n4 = n >> 2;  // arena sizes are multiples of 32 floats
+// sum the split slabs in fixed order -> gradient arena (deterministic).  Two optional extras ride in the same pass:
+//  * head partials: when the last layer's dW / db came out of k_skinny_bwd (one partial per 64-row block instead of one per
+//    split), arena offsets inside [head_off, net_stride) of each net are summed over those blocks, in block order;
+//  * the squared-norm partials of clip_grad_norm_: with `sq_part` the kernel also leaves sum(g^2) per block and bumps the
+//    optimiser's step counter -- exactly what k_sumsq (optim.hip) would compute on the reduced arena (same grid, same
+//    per-thread order, same fold), so the fused and the two-launch forms give identical bits.
+struct ReduceP {
+  const float* slabs; int splits; long long n;
+  float* out;
+  const float* head_part; int head_blocks; int n_nets; long long net_stride, head_off, head_floats;
+  float* sq_part; int32_t* step_dev;
+};
+
+__global__ __launch_bounds__(256) void k_reduce_slabs(ReduceP p) {
+  __shared__ float shw[4];
+  const long long n4 = p.n >> 2;  // arena sizes are multiples of 32 floats
+  float acc = 0.f;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    float4 s = reinterpret_cast<const float4*>(slabs)[i];
-    for (int k = 1; k < splits; ++k) {
-      const float4 t = reinterpret_cast<const float4*>(slabs + (long long)k * n)[i];
-      s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    const long long off = i << 2;
+    const long long net = p.head_blocks > 0 ? off / p.net_stride : 0;
+    const long long rel = off - net * p.net_stride;
+    float4 s;
+    if (p.head_blocks > 0 && rel >= p.head_off) {   // block boundaries are multiples of 32 floats: a quad never straddles
+      const float* hp = p.head_part + net * p.head_floats + (rel - p.head_off);
+      s = *reinterpret_cast<const float4*>(hp);
+      for (int k = 1; k < p.head_blocks; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(hp + (long long)k * p.n_nets * p.head_floats);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+    } else {
+      s = reinterpret_cast<const float4*>(p.slabs)[i];
+      for (int k = 1; k < p.splits; ++k) {
+        const float4 t = reinterpret_cast<const float4*>(p.slabs + (long long)k * p.n)[i];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
     }
-    reinterpret_cast<float4*>(out)[i] = s;
+    reinterpret_cast<float4*>(p.out)[i] = s;
+    acc += (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
+  }
+  if (!p.sq_part) return;
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    p.sq_part[blockIdx.x] = (shw[0] + shw[1]) + (shw[2] + shw[3]);
+    if (blockIdx.x == 0 && p.step_dev) p.step_dev[0] += 1;
   }
 }
 
-extern "C" int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
-                                 const float* acts, const float* dy, float* grads, int32_t splits, float* dx,
-                                 int64_t ld_dx, int32_t dx_col0, int32_t dx_cols, const float* dx_tanh_of,
-                                 int64_t ld_tanh, float* ws, int64_t ws_floats, pqlk_stream_t stream) {
+// grid of the squared-norm partials (must equal adamw_impl's k_sumsq grid in optim.hip)
+extern "C" int32_t pqlk_sumsq_parts(int64_t n) {
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  return (int32_t)blocks;
+}
+
+static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                             const float* acts, const float* dy, float* grads, int32_t splits, float* dx,
+                             int64_t ld_dx, int32_t dx_col0, int32_t dx_cols, const float* dx_tanh_of,
+                             int64_t ld_tanh, float* ws, int64_t ws_floats, float* sq_part, int32_t* step_dev,
+                             pqlk_stream_t stream) {
   int rc = desc_ok(d);
   if (rc) return rc;
   PQLK_REQUIRE(params && x && acts && dy && ws, PQLK_E_NULL);
@@ -814,8 +864,9 @@ extern "C" int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const
   PQLK_REQUIRE(grads || dx, PQLK_E_NULL);
   if (grads) PQLK_REQUIRE(splits >= 1 && splits <= 64, PQLK_E_SHAPE);
   if (!grads) splits = 0;
-  PQLK_REQUIRE(ws_floats >= 2 * (int64_t)d->n_nets * b * max_hidden_ld(d) + (int64_t)splits * pqlk_mlp_param_floats(d),
-               PQLK_E_WORKSPACE);
+  PQLK_REQUIRE(ws_floats >= 2 * (int64_t)d->n_nets * b * max_hidden_ld(d) + (int64_t)splits * pqlk_mlp_param_floats(d) +
+                                (grads ? head_part_floats(d, b) : 0), PQLK_E_WORKSPACE);
+  PQLK_REQUIRE(!sq_part || grads, PQLK_E_NULL);
   if (dx) {
     PQLK_REQUIRE(ld_dx % 32 == 0, PQLK_E_ALIGN);
     if (dx_tanh_of) PQLK_REQUIRE(dx_col0 >= 0 && dx_cols > 0 && dx_col0 + dx_cols <= d->dims[0] && ld_dx >= dx_cols,
@@ -828,6 +879,8 @@ extern "C" int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const
   const int64_t dbuf = (int64_t)d->n_nets * b * max_hidden_ld(d);
   float* dact[2] = {ws, ws + dbuf};
   float* slabs = ws + 2 * dbuf;
+  float* head_part = slabs + (int64_t)splits * arena;
+  int head_blocks = 0;   // > 0: the last layer's dW / db are per-block partials in head_part
   hipStream_t st = pqlk_s(stream);
 
   const float* cur_dy = dy;  // (n_nets, b, ld(out_l))
@@ -852,6 +905,17 @@ extern "C" int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const
       q.X = in; q.ldx = (int)in_ld; q.sX = in_stride;
       q.dY = cur_dy; q.ldy = (int)ld_out; q.sY = b * ld_out;
       q.M = (int)b; q.N = d->dims[l + 1]; q.K = (int)ld_in; q.ldk = (int)ld_in; q.ldc = (int)ld_out;
+      if (grads && l > 0 && skinny_bwd_fused_ok(q.N, q.K)) {   // dX + dW + db in one pass over the activations
+        q.W = params + w_off; q.sW = net_stride;
+        q.C = dact[flip]; q.sC = b * ld_in;
+        q.epi = SK_EPI_DELU;
+        head_blocks = skinny_bwd_blocks(b);
+        rc = launch_skinny_bwd(q, d->n_nets, head_part, (long long)(net_stride - w_off), st);
+        if (rc) return rc;
+        cur_dy = dact[flip];
+        flip ^= 1;
+        continue;
+      }
       if (grads) {
         q.dW = slabs + w_off; q.dB = slabs + b_off; q.sW = net_stride; q.sBias = net_stride; q.sSplit = arena;
         q.splits = splits; q.rows_per_split = (int)pqlk_round_up((b + splits - 1) / splits, KT_MAX);
@@ -919,10 +983,42 @@ extern "C" int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const
     }
   }
   if (grads) {
-    int blocks = (int)((arena / 4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, st, slabs, splits, (long long)arena, grads);
+    ReduceP r = {};
+    r.slabs = slabs; r.splits = splits; r.n = arena; r.out = grads;
+    r.head_part = head_part; r.head_blocks = head_blocks; r.n_nets = d->n_nets; r.net_stride = net_stride;
+    int64_t w_last, b_last;
+    pqlk_mlp_layer_offsets(d, L - 1, &w_last, &b_last);
+    r.head_off = w_last; r.head_floats = net_stride - w_last;
+    r.sq_part = sq_part; r.step_dev = step_dev;
+    int blocks;
+    if (sq_part) {
+      blocks = pqlk_sumsq_parts(arena);   // the partials must be k_sumsq's
+    } else {
+      blocks = (int)((arena / 4 + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+    }
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, st, r);
     PQLK_LAUNCH_CHECK();
   }
   return PQLK_OK;
+}
+
+extern "C" int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                                 const float* acts, const float* dy, float* grads, int32_t splits, float* dx,
+                                 int64_t ld_dx, int32_t dx_col0, int32_t dx_cols, const float* dx_tanh_of,
+                                 int64_t ld_tanh, float* ws, int64_t ws_floats, pqlk_stream_t stream) {
+  return mlp_backward_impl(d, params, x, ldx, b, acts, dy, grads, splits, dx, ld_dx, dx_col0, dx_cols, dx_tanh_of, ld_tanh, ws,
+                           ws_floats, nullptr, nullptr, stream);
+}
+
+// Same, and the gradient's squared-norm partials + the optimiser's step increment come out of the final reduction pass:
+// follow with pqlk_adamw_polyak_fused(prenorm = 1).  Not for data parallel (the all-reduce sits between the two).
+extern "C" int pqlk_mlp_backward_norm(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                                      const float* acts, const float* dy, float* grads, int32_t splits, float* dx,
+                                      int64_t ld_dx, int32_t dx_col0, int32_t dx_cols, const float* dx_tanh_of,
+                                      int64_t ld_tanh, float* ws, int64_t ws_floats, float* sumsq_part, int32_t* step_dev,
+                                      pqlk_stream_t stream) {
+  PQLK_REQUIRE(grads && sumsq_part && step_dev, PQLK_E_NULL);
+  return mlp_backward_impl(d, params, x, ldx, b, acts, dy, grads, splits, dx, ld_dx, dx_col0, dx_cols, dx_tanh_of, ld_tanh, ws,
+                           ws_floats, sumsq_part, step_dev, stream);
 }

@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_td_mse(const float* __restrict__ q, con
 extern "C" int pqlk_td_mse_loss(const float* q, const float* qt, int64_t ld, const float* rew, const float* done,
                                 float gamma_n, int64_t b, float* dy, float* loss_out, const int32_t* slot_dev,
                                 int32_t ring_len, float* scratch, pqlk_stream_t stream) {
-  PQLK_REQUIRE(q && qt && rew && done && dy && loss_out && scratch, PQLK_E_NULL);
+  PQLK_REQUIRE(q && qt && rew && done && dy && scratch, PQLK_E_NULL);
   PQLK_REQUIRE(!slot_dev || ring_len > 0, PQLK_E_SHAPE);
   PQLK_REQUIRE(b > 0, PQLK_E_SHAPE);
   PQLK_REQUIRE(ld >= 32 && ld % 32 == 0, PQLK_E_ALIGN);
@@ -62,6 +62,7 @@ extern "C" int pqlk_td_mse_loss(const float* q, const float* qt, int64_t ld, con
   if (blocks > LOSS_MAX_BLOCKS) blocks = LOSS_MAX_BLOCKS;
   hipLaunchKernelGGL(k_td_mse, dim3(blocks), dim3(256), 0, pqlk_s(stream), q, qt, ld, rew, done, gamma_n, b, dy, scratch);
   PQLK_LAUNCH_CHECK();
+  if (!loss_out) return PQLK_OK;   // partials stay in scratch[0, pqlk_loss_parts(b, 1)): folded by pqlk_adamw_polyak_fused
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, pqlk_s(stream), scratch, blocks, 1.0f / (float)b, loss_out,
                      slot_dev, (int)ring_len);
   PQLK_LAUNCH_CHECK();
@@ -188,7 +189,7 @@ extern "C" int pqlk_c51_bce_loss(const float* logits, const float* logits_t, int
                                  const float* done, const float* support, float gamma_n, float v_min, float v_max,
                                  int64_t b, float* dy, float* loss_out, const int32_t* slot_dev, int32_t ring_len,
                                  float* proj_out, float* scratch, pqlk_stream_t stream) {
-  PQLK_REQUIRE(logits && logits_t && rew && done && support && dy && loss_out && scratch, PQLK_E_NULL);
+  PQLK_REQUIRE(logits && logits_t && rew && done && support && dy && scratch, PQLK_E_NULL);
   PQLK_REQUIRE(!slot_dev || ring_len > 0, PQLK_E_SHAPE);
   PQLK_REQUIRE(b > 0 && k >= 2, PQLK_E_SHAPE);
   PQLK_REQUIRE(k <= 64, PQLK_E_UNSUPPORTED);
@@ -199,6 +200,7 @@ extern "C" int pqlk_c51_bce_loss(const float* logits, const float* logits_t, int
   hipLaunchKernelGGL(k_c51_bce, dim3(blocks), dim3(256), 0, pqlk_s(stream), logits, logits_t, ld, (int)k, rew, done,
                      support, gamma_n, v_min, v_max, dz, b, dy, proj_out, scratch);
   PQLK_LAUNCH_CHECK();
+  if (!loss_out) return PQLK_OK;   // partials stay in scratch[0, pqlk_loss_parts(b, k))
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, pqlk_s(stream), scratch, blocks,
                      1.0f / ((float)b * (float)k), loss_out, slot_dev, (int)ring_len);
   PQLK_LAUNCH_CHECK();
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void k_dpg_dist(const float* __restrict__ logi
 extern "C" int pqlk_dpg_loss(const float* q, int64_t ld, int32_t k, const float* support, int64_t b, float* dy,
                              float* loss_out, const int32_t* slot_dev, int32_t ring_len, float* scratch,
                              pqlk_stream_t stream) {
-  PQLK_REQUIRE(q && dy && loss_out && scratch, PQLK_E_NULL);
+  PQLK_REQUIRE(q && dy && scratch, PQLK_E_NULL);
   PQLK_REQUIRE(!slot_dev || ring_len > 0, PQLK_E_SHAPE);
   PQLK_REQUIRE(b > 0 && k >= 1, PQLK_E_SHAPE);
   PQLK_REQUIRE(k <= 64, PQLK_E_UNSUPPORTED);
@@ -276,8 +278,16 @@ extern "C" int pqlk_dpg_loss(const float* q, int64_t ld, int32_t k, const float*
     hipLaunchKernelGGL(k_dpg_dist, dim3(blocks), dim3(256), 0, pqlk_s(stream), q, ld, (int)k, support, b, dy, scratch);
   }
   PQLK_LAUNCH_CHECK();
+  if (!loss_out) return PQLK_OK;   // partials stay in scratch[0, pqlk_loss_parts(b, k))
   hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, pqlk_s(stream), scratch, blocks, -1.0f / (float)b, loss_out,
                      slot_dev, (int)ring_len);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
+}
+
+// number of per-block loss partials the loss entry points leave in `scratch` (k = 1: scalar heads; k > 1: one wave per row)
+extern "C" int32_t pqlk_loss_parts(int64_t b, int32_t k) {
+  int64_t blocks = k <= 1 ? (b + 255) / 256 : (b + 3) / 4;
+  if (blocks > LOSS_MAX_BLOCKS) blocks = LOSS_MAX_BLOCKS;
+  return (int32_t)blocks;
 }

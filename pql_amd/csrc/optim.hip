@@ -65,13 +65,32 @@ struct AdamC {
   double lr, b1d, b2d;
 };
 
+// A pending loss fold carried by the optimiser launch: block 0 sums the loss kernel's per-block partials exactly like
+// k_sum_partials (loss.hip) would -- same per-thread order, same tree -- and writes ring slot (t - 1) % ring_len, t = the
+// step counter AFTER this step's increment (the slot the stand-alone fold would have used before it).
+struct LossFold {
+  const float* part; int n; float scale; float* ring; int ring_len;
+};
+
 __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                float* __restrict__ v, float* __restrict__ target, int64_t n,
                                                const float* __restrict__ part, int nparts, AdamC c,
                                                const int32_t* __restrict__ step_dev, float* __restrict__ gnorm_out,
-                                               PackSpec ps) {
+                                               PackSpec ps, LossFold lf) {
   __shared__ float sh[256];
   __shared__ float s_coef, s_step_size, s_bc2_sqrt;
+  if (lf.part && blockIdx.x == 0) {   // block-uniform
+    float ls = 0.f;
+    for (int i = threadIdx.x; i < lf.n; i += 256) ls += lf.part[i];
+    sh[threadIdx.x] = ls;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) lf.ring[(step_dev[0] - 1) % lf.ring_len] = sh[0] * lf.scale;
+    __syncthreads();
+  }
   // every block re-reduces the (<= 1024) partials in the same fixed order -> identical clip factor
   float s = 0.f;
   for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
@@ -153,15 +172,17 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
 
 static int adamw_impl(float* p, float* g, float* m, float* v, float* target, int64_t n, float grad_scale, float max_norm, float lr,
                       float b1, float b2, float eps, float wd, float tau, int32_t* step_dev, float* gnorm_out, float* scratch,
-                      const PackSpec& ps, pqlk_stream_t stream) {
+                      const PackSpec& ps, pqlk_stream_t stream, bool prenorm = false, LossFold lf = LossFold{}) {
   PQLK_REQUIRE(p && g && m && v && step_dev && scratch, PQLK_E_NULL);
   PQLK_REQUIRE(n > 0, PQLK_E_SHAPE);
   PQLK_REQUIRE(pqlk_aligned16(g), PQLK_E_ALIGN);
   int blocks = (int)((n / 4 + 255) / 256);
   if (blocks < 1) blocks = 1;
   if (blocks > OPT_MAX_BLOCKS) blocks = OPT_MAX_BLOCKS;
-  hipLaunchKernelGGL(k_sumsq, dim3(blocks), dim3(256), 0, pqlk_s(stream), g, n, scratch, step_dev);
-  PQLK_LAUNCH_CHECK();
+  if (!prenorm) {   // prenorm: `scratch` already holds these partials and the step counter is bumped (pqlk_mlp_backward_norm)
+    hipLaunchKernelGGL(k_sumsq, dim3(blocks), dim3(256), 0, pqlk_s(stream), g, n, scratch, step_dev);
+    PQLK_LAUNCH_CHECK();
+  }
   AdamC c;
   // scalar constants are formed in double (python floats in torch) and rounded once to fp32
   c.lr_wd_decay = (float)(1.0 - (double)lr * (double)wd);
@@ -179,7 +200,7 @@ static int adamw_impl(float* p, float* g, float* m, float* v, float* target, int
   int blocks2 = (int)(((n + 3) / 4 + 255) / 256);   // one 16-B quad per thread
   if (blocks2 > 2048) blocks2 = 2048;
   hipLaunchKernelGGL(k_adamw, dim3(blocks2), dim3(256), 0, pqlk_s(stream), p, g, m, v, target, n, scratch, blocks, c, step_dev,
-                     gnorm_out, ps);
+                     gnorm_out, ps, lf);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }
@@ -193,17 +214,14 @@ extern "C" int pqlk_clip_adamw_polyak(float* p, float* g, float* m, float* v, fl
 
 // Same, for the arena of an MLP described by `d`, also refreshing the fragment-ordered copies of the hidden-layer
 // weights (pqlk_mlp_pack layout): packed_p for the parameters, packed_t (may be NULL) for the Polyak target.
-extern "C" int pqlk_clip_adamw_polyak_pack(const PqlMlpDesc* d, float* p, float* g, float* m, float* v, float* target,
-                                           float* packed_p, float* packed_t, float grad_scale, float max_norm, float lr, float b1,
-                                           float b2, float eps, float wd, float tau, int32_t* step_dev, float* gnorm_out,
-                                           float* scratch, pqlk_stream_t stream) {
+static int build_pack_spec(const PqlMlpDesc* d, float* packed_p, float* packed_t, PackSpec& ps) {
   PQLK_REQUIRE(d && packed_p, PQLK_E_NULL);
   PQLK_REQUIRE(d->n_layers >= 2 && d->n_layers <= PQLK_MAX_LAYERS && d->n_nets >= 1 && d->n_nets <= 2, PQLK_E_SHAPE);
   PQLK_REQUIRE((d->n_layers - 1) * d->n_nets <= PACK_MAX, PQLK_E_UNSUPPORTED);
   PQLK_REQUIRE(pqlk_mlp_packed_floats(d) > 0, PQLK_E_UNSUPPORTED);
   const int64_t net_stride = pqlk_mlp_net_stride(d);
   const int64_t packed_stride = pqlk_mlp_packed_floats(d) / d->n_nets;
-  PackSpec ps = {};
+  ps = PackSpec{};
   ps.packed_p = packed_p;
   ps.packed_t = packed_t;
   for (int net = 0; net < d->n_nets; ++net) {
@@ -220,8 +238,43 @@ extern "C" int pqlk_clip_adamw_polyak_pack(const PqlMlpDesc* d, float* p, float*
       p_off += N * K;
     }
   }
+  return PQLK_OK;
+}
+
+extern "C" int pqlk_clip_adamw_polyak_pack(const PqlMlpDesc* d, float* p, float* g, float* m, float* v, float* target,
+                                           float* packed_p, float* packed_t, float grad_scale, float max_norm, float lr, float b1,
+                                           float b2, float eps, float wd, float tau, int32_t* step_dev, float* gnorm_out,
+                                           float* scratch, pqlk_stream_t stream) {
+  PackSpec ps;
+  const int rc = build_pack_spec(d, packed_p, packed_t, ps);
+  if (rc) return rc;
   return adamw_impl(p, g, m, v, target, pqlk_mlp_param_floats(d), grad_scale, max_norm, lr, b1, b2, eps, wd, tau, step_dev,
                     gnorm_out, scratch, ps, stream);
+}
+
+// The optimiser launch of a fused learner step.  packed_p may be NULL (no fragment-ordered copies to refresh).
+//   prenorm != 0 : `scratch` already holds the gradient's squared-norm partials and `step_dev` is already incremented -- both
+//                  left by pqlk_mlp_backward_norm -- so the k_sumsq launch is skipped;
+//   loss_part    : optional per-block loss partials (pqlk_*_loss called with loss_out = NULL): block 0 folds loss_parts of
+//                  them, times loss_scale, into loss_ring[(t - 1) % ring_len] instead of a separate one-block launch.
+extern "C" int pqlk_adamw_polyak_fused(const PqlMlpDesc* d, float* p, float* g, float* m, float* v, float* target,
+                                       float* packed_p, float* packed_t, float grad_scale, float max_norm, float lr, float b1,
+                                       float b2, float eps, float wd, float tau, int32_t* step_dev, float* gnorm_out,
+                                       float* scratch, int32_t prenorm, const float* loss_part, int32_t loss_parts,
+                                       float loss_scale, float* loss_ring, int32_t ring_len, pqlk_stream_t stream) {
+  PQLK_REQUIRE(d, PQLK_E_NULL);
+  PackSpec ps = {};
+  if (packed_p) {
+    const int rc = build_pack_spec(d, packed_p, packed_t, ps);
+    if (rc) return rc;
+  }
+  LossFold lf = {};
+  if (loss_part) {
+    PQLK_REQUIRE(loss_ring && ring_len > 0 && loss_parts > 0, PQLK_E_SHAPE);
+    lf.part = loss_part; lf.n = loss_parts; lf.scale = loss_scale; lf.ring = loss_ring; lf.ring_len = ring_len;
+  }
+  return adamw_impl(p, g, m, v, target, pqlk_mlp_param_floats(d), grad_scale, max_norm, lr, b1, b2, eps, wd, tau, step_dev,
+                    gnorm_out, scratch, ps, stream, prenorm != 0, lf);
 }
 
 __global__ __launch_bounds__(256) void k_polyak(float* __restrict__ target, const float* __restrict__ cur, int64_t n,

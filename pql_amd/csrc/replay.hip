@@ -240,13 +240,20 @@ __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __rest
 // decode, destination and normalisation constants of a lane depend only on its chunk index, so they are computed ONCE
 // per kernel and the per-row work is load -> (sub, IEEE div, clamp) x4 -> one or two 16-B stores.  The generic kernel
 // above re-decodes the field per row and is instruction-issue bound (~450 instructions per row).
+// tuning hooks (pqlk_tune_gather): 0 = automatic
+static int g_gather_R = 0, g_gather_waves_per_cu = 0, g_gather_nopad = 0;
+extern "C" int pqlk_tune_gather(int rows_in_flight, int waves_per_cu, int nopad) {
+  g_gather_R = rows_in_flight; g_gather_waves_per_cu = waves_per_cu; g_gather_nopad = nopad;
+  return PQLK_OK;
+}
+
 template <bool HAS_NORM, int R>
 __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restrict__ records, RecLayout L, int64_t capacity,
                                                             const int64_t* __restrict__ idx, int64_t b,
                                                             const float* __restrict__ mean, const float* __restrict__ var,
                                                             float eps, int clamp5, float* __restrict__ x_sa, int64_t ld_sa,
                                                             float* __restrict__ xn_sa, float* __restrict__ xn_obs, int64_t ld_o,
-                                                            float* __restrict__ o_rew, float* __restrict__ o_done) {
+                                                            float* __restrict__ o_rew, float* __restrict__ o_done, int write_pads) {
   const int lane = threadIdx.x & 63;
   const int c = lane << 2;
   const int nchunk = L.used >> 2;
@@ -334,6 +341,7 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
         if (o_rew) o_rew[r] = x.x;
         if (o_done) o_done[r] = x.y;
       }
+      if (!write_pads) continue;
       if (pad_vec) {   // pads start on a 16-B boundary: one 16-B zero store per lane
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lane < (npad_sa >> 2)) {
@@ -391,15 +399,21 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
   if (fast) {
     // rows in flight per wave: 2 up to 16 Ki rows (more waves, shorter dependent idx -> row chain: 9.3 vs 10.5 us at 8192),
     // 4 beyond (same time at 32 Ki rows, fewer blocks)
-    const int R = b <= 16384 ? 2 : 4;
+    int R = b <= 16384 ? 2 : 4;
+    if (g_gather_R) R = g_gather_R;
     int64_t fb = (b + 4 * R - 1) / (4 * R);
     if (fb > 2048) fb = 2048;
+    if (g_gather_waves_per_cu) { const int64_t cap = 256 * (int64_t)g_gather_waves_per_cu / 4; if (fb > cap) fb = cap; }
     const dim3 g((unsigned)fb), t(256);
+    const int write_pads = g_gather_nopad ? 0 : 1;
 #define PQLK_GATHER_FAST(NORM, RR) \
     hipLaunchKernelGGL((k_replay_gather_fast<NORM, RR>), g, t, 0, pqlk_s(stream), ring->records, L, ring->capacity, idx, b, mean, var, \
-                       eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done)
-    if (mean) { if (R == 2) PQLK_GATHER_FAST(true, 2); else PQLK_GATHER_FAST(true, 4); }
-    else { if (R == 2) PQLK_GATHER_FAST(false, 2); else PQLK_GATHER_FAST(false, 4); }
+                       eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done, write_pads)
+#define PQLK_GATHER_FAST_R(NORM) \
+    do { if (R == 1) PQLK_GATHER_FAST(NORM, 1); else if (R == 2) PQLK_GATHER_FAST(NORM, 2); else if (R == 4) PQLK_GATHER_FAST(NORM, 4); \
+         else PQLK_GATHER_FAST(NORM, 8); } while (0)
+    if (mean) PQLK_GATHER_FAST_R(true); else PQLK_GATHER_FAST_R(false);
+#undef PQLK_GATHER_FAST_R
 #undef PQLK_GATHER_FAST
     PQLK_LAUNCH_CHECK();
     return PQLK_OK;

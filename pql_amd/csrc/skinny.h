@@ -268,6 +268,164 @@ __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------- dX + dW + db in ONE pass
+// The head's dX and dW both stream the same (M, K) activations and the same (M, N) dY: one kernel reads them once.
+//   dX[m, :] = (sum_n dY[m, n] W[n, :]) * ELU'(X[m, :])        (written as it is formed)
+//   dW[n, :] = sum_m dY[m, n] X[m, :],  db[n] = sum_m dY[m, n]   (per-block partial, folded later in block order)
+// One wave per batch row (64 lanes x 16 B cover K = 256 floats; CH = ceil(K / 256) chunks per lane), 4 rows in flight
+// per wave, SKB_ROWS rows per block so that B = 8192 x 2 nets gives 256 blocks.  Every block leaves its partial
+// (N x ldk weights, then ld(N) biases: the arena layout of the layer) in `part[block][group]`; the slab-reduction kernel
+// folds the blocks in index order (deterministic, no atomics).  NB = compile-time bound on N (register arrays).
+#define SKB_ROWS 64
+template <int NB, int CH>
+__global__ __launch_bounds__(256) void k_skinny_bwd(SkinnyP p, float* __restrict__ part, long long part_floats) {
+  extern __shared__ __attribute__((aligned(16))) float sk_lds[];   // W (N, K) | red[3] (N, K) | dbred[4][16]
+  const int g = blockIdx.y;
+  const int kq = p.K >> 2;
+  const int NK = p.N * p.K;
+  float* w_lds = sk_lds;
+  float* red = sk_lds + NK;
+  float* dbred = red + 3 * NK;
+  const float* W = p.W + (long long)g * p.sW;
+  for (int i = threadIdx.x; i < p.N * kq; i += 256) {
+    const int n = i / kq, q = i % kq;
+    reinterpret_cast<float4*>(w_lds)[i] = *reinterpret_cast<const float4*>(W + (long long)n * p.ldk + 4 * q);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* X = p.X + (long long)g * p.sX;
+  const float* dY = p.dY + (long long)g * p.sY;
+  float* C = p.C + (long long)g * p.sC;
+  float4 acc[NB][CH];
+#pragma unroll
+  for (int n = 0; n < NB; ++n)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[n][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float dbacc = 0.f;   // lane n < N: sum of dY[:, n] over this wave's rows
+  const int m_blk = blockIdx.x * SKB_ROWS;
+  // rows m_blk + wave + 4 j, j = 0..15, taken four at a time: all 4 x CH activation loads and the 4 dY loads of a group
+  // are requested before the first is used
+  for (int j0 = 0; j0 < SKB_ROWS / 4; j0 += 4) {
+    float4 xv[4][CH];
+    float dyl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m_blk + wave + 4 * (j0 + u);
+      const bool ok = m < p.M;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int q = lane + 64 * c;
+        xv[u][c] = (ok && q < kq) ? *reinterpret_cast<const float4*>(X + (long long)m * p.ldx + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      dyl[u] = (ok && lane < p.N) ? dY[(long long)m * p.ldy + lane] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int m = m_blk + wave + 4 * (j0 + u);
+      float dn[NB];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) dn[n] = __shfl(dyl[u], n, 64);
+      dbacc += dyl[u];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int q = lane + 64 * c;
+        if (q < kq) {
+          float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 x = xv[u][c];
+#pragma unroll
+          for (int n = 0; n < NB; ++n) {
+            if (n < p.N) {
+              const float4 w = reinterpret_cast<const float4*>(w_lds)[n * kq + q];
+              a.x += dn[n] * w.x; a.y += dn[n] * w.y; a.z += dn[n] * w.z; a.w += dn[n] * w.w;
+              acc[n][c].x += dn[n] * x.x; acc[n][c].y += dn[n] * x.y; acc[n][c].z += dn[n] * x.z; acc[n][c].w += dn[n] * x.w;
+            }
+          }
+          if (p.epi == SK_EPI_DELU) {
+            a.x = x.x > 0.f ? a.x : a.x * (x.x + 1.f);
+            a.y = x.y > 0.f ? a.y : a.y * (x.y + 1.f);
+            a.z = x.z > 0.f ? a.z : a.z * (x.z + 1.f);
+            a.w = x.w > 0.f ? a.w : a.w * (x.w + 1.f);
+          }
+          if (m < p.M) *reinterpret_cast<float4*>(C + (long long)m * p.ldk + 4 * q) = a;
+        }
+      }
+    }
+  }
+  // fold the four waves in wave order: waves 1..3 park their sums in LDS, wave 0 adds them 0 + 1 + 2 + 3
+  if (wave > 0) {
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+      if (n < p.N)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int q = lane + 64 * c;
+          if (q < kq) reinterpret_cast<float4*>(red + (wave - 1) * NK)[n * kq + q] = acc[n][c];
+        }
+  }
+  if (lane < 16) dbred[wave * 16 + lane] = dbacc;
+  __syncthreads();
+  if (wave == 0) {
+    float* out = part + ((long long)blockIdx.x * gridDim.y + g) * part_floats;
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+      if (n < p.N)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+          const int q = lane + 64 * c;
+          if (q < kq) {
+            float4 s = acc[n][c];
+#pragma unroll
+            for (int w = 0; w < 3; ++w) {
+              const float4 t = reinterpret_cast<const float4*>(red + w * NK)[n * kq + q];
+              s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            *reinterpret_cast<float4*>(out + (long long)n * p.ldk + 4 * q) = s;
+          }
+        }
+    if (lane < p.ldc)   // ldc = pqlk_ld(N) <= 32: bias block with zero pad
+      out[(long long)p.N * p.ldk + lane] = lane < p.N ? ((dbred[lane] + dbred[16 + lane]) + dbred[32 + lane]) + dbred[48 + lane] : 0.f;
+  }
+}
+
+// fused backward of the head is used when the per-lane accumulators (N x CH float4) stay within 16 registers quads
+static inline int skinny_bwd_ch(int k_padded) { const int c = (k_padded + 255) / 256; return c <= 2 ? c : 4; }   // template CH
+static inline int skinny_bwd_nb(int n_out) { return n_out == 1 ? 1 : (n_out <= 4 ? 4 : (n_out <= 8 ? 8 : 16)); }       // template NB
+static inline bool skinny_bwd_fused_ok(int n_out, int k_padded) {
+  return n_out <= SKINNY_MAX_N && k_padded <= SKINNY_MAX_K && skinny_bwd_nb(n_out) * skinny_bwd_ch(k_padded) <= 16;
+}
+static inline int skinny_bwd_blocks(int64_t m) { return (int)((m + SKB_ROWS - 1) / SKB_ROWS); }
+
+template <int NB, int CH>
+static int launch_skinny_bwd_t(const SkinnyP& p, int groups, float* part, long long part_floats, hipStream_t st) {
+  const size_t sh = ((size_t)4 * p.N * p.K + 64) * sizeof(float);
+  static PqlkPerDeviceOnce attr_once;
+  if (attr_once.need()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skinny_bwd<NB, CH>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (4 * 4096 + 64) * (int)sizeof(float));   // N x K <= 16 x 256 floats
+    if (e != hipSuccess) return -(int)e;
+  }
+  hipLaunchKernelGGL((k_skinny_bwd<NB, CH>), dim3(skinny_bwd_blocks(p.M), groups), dim3(256), sh, st, p, part, part_floats);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}
+
+static int launch_skinny_bwd(const SkinnyP& p, int groups, float* part, long long part_floats, hipStream_t st) {
+  const int ch = skinny_bwd_ch(p.K);
+  if (p.N == 1) {
+    if (ch == 1) return launch_skinny_bwd_t<1, 1>(p, groups, part, part_floats, st);
+    if (ch == 2) return launch_skinny_bwd_t<1, 2>(p, groups, part, part_floats, st);
+    return launch_skinny_bwd_t<1, 4>(p, groups, part, part_floats, st);
+  }
+  if (p.N <= 4) {
+    if (ch == 1) return launch_skinny_bwd_t<4, 1>(p, groups, part, part_floats, st);
+    if (ch == 2) return launch_skinny_bwd_t<4, 2>(p, groups, part, part_floats, st);
+    return launch_skinny_bwd_t<4, 4>(p, groups, part, part_floats, st);
+  }
+  if (p.N <= 8 && ch <= 2) return ch == 1 ? launch_skinny_bwd_t<8, 1>(p, groups, part, part_floats, st)
+                                          : launch_skinny_bwd_t<8, 2>(p, groups, part, part_floats, st);
+  return launch_skinny_bwd_t<16, 1>(p, groups, part, part_floats, st);   // N <= 16, K <= 256 (skinny_bwd_fused_ok)
+}
+
 // forward: one wave_sum per output, so only worth it for a handful of outputs (the Q head); backward variants
 // stream and stay ahead of a 64x64 MFMA tile up to 16 outputs.
 static inline bool skinny_fwd_ok(int n_out, int k_padded) { return n_out <= 4 && k_padded <= SKINNY_MAX_K; }

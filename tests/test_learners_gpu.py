@@ -254,6 +254,41 @@ def test_cfg5_humanoid_nstep5_batch32768_v_step_vs_oracle(dev):
     _compare_nets(p.actor, (pr.actor,))
 
 
+@pytest.mark.parametrize("distl", [False, True])
+def test_fused_tail_is_bit_identical_to_the_separate_launches(dev, distl):
+    """algo.fused_tail folds the loss reduction into the optimiser launch and clip_grad_norm_'s sum of squares into backward's
+    slab reduction (2 launches fewer per step).  Same partials, same order: parameters, optimiser state and the loss ring
+    must come out bit for bit as with the stand-alone launches (the data-parallel path still uses those)."""
+    from pql_amd.algo.pql_p_learner import PQLPLearner
+    from pql_amd.algo.pql_v_learner import PQLVLearner
+    O, A, B, cap, K = 88, 16, 4096, 8000, 51
+    outs = []
+    for tail in (True, False):
+        cfg = make_cfg(distl, B=B, memory=cap, hidden=[512, 512, 256])
+        cfg.algo.fused_tail = tail
+        v = PQLVLearner((O,), A, cfg); p = PQLPLearner((O,), A, cfg)
+        assert v._fused_tail is tail and p._fused_tail is tail
+        v.critic.load_state_dict(_sd(dd.doubleq_state(O, A, K if distl else 1, 61, (512, 512, 256))))
+        v.critic_target.arena.data.copy_(v.critic.arena.data)
+        p.actor.load_state_dict(_sd(dd.mlp_state(O, A, 63, (512, 512, 256))))
+        data = tuple(t.to(dev) for t in _fill(O, A, cap - 7, 377))
+        norm = (T(dd.uniform((O,), 831, -0.5, 0.5)).to(dev), T(dd.uniform((O,), 832, 0.5, 2.0)).to(dev), 1e-4)
+        critic, _, _ = v.update(p.actor, data, norm, 0)
+        p.update(critic, data[0], norm, 0)
+        for s in range(3):
+            idx = T(dd.integers((B,), 940 + s, cap - 7)); draw = T(dd.uniform((B, A), 990 + s, -2, 2))
+            v.learn(indices=idx, noise=draw)
+            p.learn(indices=idx)
+        torch.cuda.synchronize()
+        outs.append((v.critic.arena.data.clone(), v.critic_target.arena.data.clone(), v.opt.m.clone(), v.opt.v.clone(),
+                     v.loss_ring.clone(), v.opt.gnorm.clone(), p.actor.arena.data.clone(), p.opt.v.clone(), p.loss_ring.clone(),
+                     v.opt.step.clone(), p.opt.step.clone()))
+    assert int(outs[0][-1]) == 3 and int(outs[0][-2]) == 3
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert float(outs[0][4].abs().sum()) > 0 and float(outs[0][8].abs().sum()) > 0   # the folded losses did land in the rings
+
+
 def test_graph_replay_matches_eager(dev):
     """hipGraph-captured learn() is the same launch sequence: with equal seeds it must reproduce the eager
     parameters bit for bit (same kernels, same order, same RNG offsets)."""
