@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-streams", action="store_true", help="serialise V / P / rollout on one stream")
     ap.add_argument("--no-fused", action="store_true", help="per-layer GEMM launches instead of the fused hidden-layer forward")
+    ap.add_argument("--no-fused-tail", action="store_true", help="separate loss-fold / gradient-norm launches (A/B of algo.fused_tail)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=96, help="schedule steps of the bounded CPU-oracle sample (~15 s)")
     ap.add_argument("--v-only", action="store_true", help="time free-running V-learner steps only")
@@ -96,6 +97,7 @@ def build_system(args, rank, world, device, pg, learner_device=None):
           f"device=cuda:{device.index}"]
     cfg = load_cfg(ov)
     cfg.algo.hidden_layers = hidden
+    cfg.algo.fused_tail = not getattr(args, "no_fused_tail", False)
     cfg.algo.reward_scale = 0.01   # preprocess_cfg's AllegroHand value (common.py:159-170)
     env = create_task_env(cfg, env_offset=rank * args.num_envs)
     actor = PQLActor(env, cfg, env_offset=rank * args.num_envs, total_envs=world * args.num_envs)
@@ -227,7 +229,7 @@ def gather_ms(v, iters=50):
     fused_actor = v.pk_actor is not None and v.pk_actor.tensor is not None
 
     def one(i):
-        L.check(L.lib.pqlk_replay_gather_fused(C.byref(v.memory.ring.desc), L.ptr(idx[i]), B, L.ptr(mean), L.ptr(var), eps, 1,
+        L.check(L.lib.pqlk_replay_gather_fused(C.byref(v.memory.ring.desc), L.ptr(idx[i]), B, L.ptr(mean), L.ptr(var), eps, 3,
                                                L.ptr(ws["x_sa"]), ws["ld_sa"], L.ptr(ws["xn_sa"]),
                                                None if fused_actor else L.ptr(ws["xn_obs"]), ws["ld_o"],
                                                L.ptr(ws["rew"]), L.ptr(ws["done"]), L.stream(v.device)))

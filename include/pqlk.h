@@ -99,7 +99,12 @@ int pqlk_replay_gather(const PqlReplayDesc* ring, const int64_t* idx, int64_t b,
  *   xn_obs (B, ld_o)   : [ norm(next_obs) | 0 ]              target-actor input      (may be NULL)
  *   rew, done (B)                                                                    (may be NULL)
  * For an obs-only ring only x_sa (obs columns + zeroed action columns) and/or xn_obs (= norm(obs)
- * with ld_o) are written (pql_p_learner.py:49-52). */
+ * with ld_o) are written (pql_p_learner.py:49-52).
+ * clamp5 is a flag word: bit 0 = apply the +-5 clamp; bit 1 (PQLK_GATHER_PADS_ZERO) = the caller guarantees that the pad
+ * columns [O+A, ld_sa) / [O, ld_o) of the destinations are already zero (allocated zeroed, written by nothing else), so
+ * the kernel does not re-zero them on every call (11 % fewer bytes stored at cfg 5). */
+#define PQLK_GATHER_CLAMP5 1
+#define PQLK_GATHER_PADS_ZERO 2
 int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t* idx, int64_t b,
                              const float* mean, const float* var, float eps, int clamp5,
                              float* x_sa, int64_t ld_sa, float* xn_sa, float* xn_obs, int64_t ld_o,
@@ -205,6 +210,13 @@ int pqlk_mlp_backward_norm(const PqlMlpDesc* d, const float* params, const float
                            const float* dx_tanh_of, int64_t ld_tanh,
                            float* ws, int64_t ws_floats, float* sumsq_part, int32_t* step_dev, pqlk_stream_t stream);
 int32_t pqlk_sumsq_parts(int64_t n);
+
+/* Tuning / test hooks of the replay gather.  pqlk_tune_gather: rows in flight per wave (1, 2, 4, 8), resident waves per CU
+ * and "skip the pad stores" for the next launches (0 = automatic).  pqlk_selftest_fastdiv: number of (x[i], s[j]) pairs for
+ * which the gather's reciprocal-based quotient differs in any bit from the IEEE quotient x / s (must be 0). */
+int pqlk_tune_gather(int rows_in_flight, int waves_per_cu, int nopad);
+int pqlk_selftest_fastdiv(const float* x, int64_t nx, const float* s, int64_t ns, unsigned long long* mismatches,
+                          pqlk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Losses.  Each writes dy (2, B, ld) for pqlk_mlp_backward and one scalar loss (device), via per-block

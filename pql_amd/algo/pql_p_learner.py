@@ -19,7 +19,7 @@ from copy import deepcopy
 import torch
 
 from pql_amd import _lib as L
-from pql_amd.algo.pql_v_learner import (LOSS_RING, LaggedLoss, _AdamState, _cfg_get, adopt_arena, allreduce_sum, apply_optimizer,
+from pql_amd.algo.pql_v_learner import (GATHER_FLAGS, LOSS_RING, LaggedLoss, _AdamState, _cfg_get, adopt_arena, allreduce_sum, apply_optimizer,
                                         apply_optimizer_fused, f32_recip, graph_collective_enabled, pump, resident_norm)
 from pql_amd.models import model_name_to_path
 from pql_amd.models.mlp import PackedWeights, default_splits, mlp_forward_raw, output_view
@@ -149,7 +149,7 @@ class PQLPLearner:
         mean, var, eps = (None, None, 0.0)
         if algo.obs_norm and self.normalize_tuple is not None:
             mean, var, eps = self.normalize_tuple
-        L.check(L.lib.pqlk_replay_gather_fused(C.byref(self.ring.desc), L.ptr(idx), B, L.ptr(mean), L.ptr(var), float(eps), 1,
+        L.check(L.lib.pqlk_replay_gather_fused(C.byref(self.ring.desc), L.ptr(idx), B, L.ptr(mean), L.ptr(var), float(eps), GATHER_FLAGS,
                                                L.ptr(ws["x_sa"]), ws["ld_sa"], None, L.ptr(ws["x_obs"]), ws["ld_o"], None, None,
                                                st))
         al, cl = self.actor.layout, self.critic.layout

@@ -32,6 +32,8 @@ from pql_amd.utils import handoff as H
 from pql_amd.utils.common import Tracker, load_class_from_path
 
 LOSS_RING = 5  # Tracker(5) of the reference (:54)
+# gather: +-5 clamp (bit 0); the learners' input tiles are allocated zeroed and nothing else writes their pad columns (bit 1)
+GATHER_FLAGS = 1 | 2
 
 
 def _cfg_get(node, name, default=None):
@@ -349,7 +351,7 @@ class PQLVLearner:
         # the fused actor forward masks everything past column O while staging its tile, so it can read norm(next_obs)
         # straight out of the target critic's input tile: one gather output (B x ld(O) floats) less to write
         actor_in_sa = self.pk_actor is not None and self.pk_actor.tensor is not None
-        L.check(L.lib.pqlk_replay_gather_fused(C.byref(self.memory.ring.desc), L.ptr(idx), B, L.ptr(mean), L.ptr(var), eps, 1,
+        L.check(L.lib.pqlk_replay_gather_fused(C.byref(self.memory.ring.desc), L.ptr(idx), B, L.ptr(mean), L.ptr(var), eps, GATHER_FLAGS,
                                                L.ptr(ws["x_sa"]), ws["ld_sa"], L.ptr(ws["xn_sa"]),
                                                None if actor_in_sa else L.ptr(ws["xn_obs"]),
                                                ws["ld_o"], L.ptr(ws["rew"]), L.ptr(ws["done"]), st))

@@ -119,9 +119,66 @@ extern "C" int pqlk_replay_gather(const PqlReplayDesc* ring, const int64_t* idx,
 }
 
 // ------------------------------------------------------------------------------------------------
+// ---- x / s, correctly rounded, without the hardware's 12-instruction IEEE sequence --------------------------------
+// The normaliser divides every gathered observation by sd = sqrt(var + eps) -- the same few hundred divisors for every
+// row -- and the result has to equal torch's `(x - mean) / sqrt(var + eps)` bit for bit.  With r = RN(1 / s) formed once per
+// column by a true IEEE division, q0 = x r is within an ulp or two of x / s, and two residual corrections
+//     e = fma(-s, q, x);  q = fma(e, r, q)
+// end on RN(x / s) (Markstein's theorem: the last correction of a faithful quotient with a correctly rounded reciprocal
+// is the correctly rounded quotient) -- PROVIDED nothing leaves the normal range and s is not the one exceptional
+// significand 1.11...1b.  Everything outside that envelope takes the hardware division:
+//   columns:  s outside [2^-60, 2^60], s with an all-ones significand, s not finite   -> div_plan.exact = false
+//   elements: |x| outside [2^-60, 2^60] (subnormal, huge, inf, nan)  -> x / s;   x = +-0 -> x * r (keeps the sign)
+// tests/test_kernels_gpu.py::test_fast_division_is_ieee checks ~10^9 (x, s) pairs bit for bit (pqlk_selftest_fastdiv).
+struct DivPlan { float s, r; bool exact; };
+__device__ __forceinline__ DivPlan div_plan(float s) {
+  DivPlan p;
+  p.s = s;
+  p.r = 1.0f / s;
+  const unsigned bits = __float_as_uint(s);
+  p.exact = (s >= 8.6736174e-19f) && (s <= 1.1529215e18f) && ((bits & 0x7FFFFFu) != 0x7FFFFFu);   // 2^-60 .. 2^60
+  return p;
+}
+__device__ __forceinline__ float div_exact(float x, const DivPlan& p) {
+  const float ax = fabsf(x);
+  const float q0 = x * p.r;   // also the exact answer for x = +-0 (r > 0 finite when p.exact)
+  float e = fmaf(-p.s, q0, x);
+  float q = fmaf(e, p.r, q0);
+  e = fmaf(-p.s, q, x);
+  q = fmaf(e, p.r, q);
+  q = ax == 0.f ? q0 : q;
+  // outside the envelope: the hardware division, behind a branch the wave skips when no lane needs it
+  if (!(p.exact && (ax == 0.f || (ax >= 8.6736174e-19f && ax <= 1.1529215e18f)))) q = x / p.s;
+  return q;
+}
+
+__global__ __launch_bounds__(256) void k_selftest_fastdiv(const float* __restrict__ x, int64_t nx, const float* __restrict__ sv,
+                                                          int64_t ns, unsigned long long* __restrict__ bad) {
+  unsigned long long mine = 0;
+  for (int64_t j = blockIdx.y; j < ns; j += gridDim.y) {
+    const DivPlan p = div_plan(sv[j]);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nx; i += (int64_t)gridDim.x * 256) {
+      const float a = div_exact(x[i], p), b = x[i] / sv[j];
+      mine += (__float_as_uint(a) != __float_as_uint(b)) && !(a != a && b != b);
+    }
+  }
+  if (mine) atomicAdd(bad, mine);
+}
+
+// Test hook: counts (x[i], s[j]) pairs whose fast quotient differs in any bit from the IEEE quotient (NaN == NaN).
+extern "C" int pqlk_selftest_fastdiv(const float* x, int64_t nx, const float* s, int64_t ns, unsigned long long* mismatches,
+                                     pqlk_stream_t stream) {
+  PQLK_REQUIRE(x && s && mismatches, PQLK_E_NULL);
+  PQLK_REQUIRE(nx > 0 && ns > 0, PQLK_E_SHAPE);
+  hipLaunchKernelGGL(k_selftest_fastdiv, dim3(1024, (unsigned)(ns < 64 ? ns : 64)), dim3(256), 0, pqlk_s(stream), x, nx, s, ns,
+                     mismatches);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}
+
 // fused gather: sample + normalise (+-5 clamp) + concat into the padded GEMM input tiles.
-__device__ __forceinline__ float norm1(float x, float mean, float sd, int clamp5) {
-  float y = (x - mean) / sd;  // IEEE division: bit-identical to (x-mean)/sqrt(var+eps) evaluated by torch
+__device__ __forceinline__ float norm1(float x, float mean, const DivPlan& sd, int clamp5) {
+  float y = div_exact(x - mean, sd);  // IEEE-exact quotient: bit-identical to (x-mean)/sqrt(var+eps) evaluated by torch
   if (clamp5) y = fminf(fmaxf(y, -5.f), 5.f);
   return y;
 }
@@ -149,15 +206,15 @@ __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __rest
                                                              float eps, int clamp5, float* __restrict__ x_sa, int64_t ld_sa,
                                                              float* __restrict__ xn_sa, float* __restrict__ xn_obs,
                                                              int64_t ld_o, float* __restrict__ o_rew,
-                                                             float* __restrict__ o_done) {
+                                                             float* __restrict__ o_done, int write_pads) {
   // per-column mean and sd = sqrt(var + eps) (correctly rounded sqrtf) staged once per block: the per-element work
   // is then one subtract and one IEEE divide instead of a divide AND a square root
   __shared__ float s_mean[HAS_NORM ? GATHER_MAX_OBS : 1];
-  __shared__ float s_sd[HAS_NORM ? GATHER_MAX_OBS : 1];
+  __shared__ DivPlan s_sd[HAS_NORM ? GATHER_MAX_OBS : 1];
   if (HAS_NORM) {
     for (int c = threadIdx.x; c < L.O; c += 256) {
       s_mean[c] = mean[c];
-      s_sd[c] = sqrtf(var[c] + eps);
+      s_sd[c] = div_plan(sqrtf(var[c] + eps));
     }
     __syncthreads();
   }
@@ -222,13 +279,14 @@ __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __rest
           }
         }
       }
+      if (L.A < 0 && xs) {
+        for (int c = L.O + lane; c < sa_cols; c += 64) xs[c] = 0.f;
+      }
+      if (!write_pads) continue;
       // zero the pad columns so the GEMM K-loop can run over the padded width unchecked
       for (int c = sa_cols + lane; c < ld_sa; c += 64) {
         if (xs) xs[c] = 0.f;
         if (xns) xns[c] = 0.f;
-      }
-      if (L.A < 0 && xs) {
-        for (int c = L.O + lane; c < sa_cols; c += 64) xs[c] = 0.f;
       }
       if (xno)
         for (int c = L.O + lane; c < ld_o; c += 64) xno[c] = 0.f;
@@ -281,15 +339,17 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
     }
   }
   vecA = vecA && nvalid == 4;
-  float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  DivPlan dp[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dp[j] = div_plan(1.f);
   const bool do_norm = HAS_NORM && ncol >= 0;
   if (do_norm) {   // scalar loads: O need not be a multiple of 4; invalid tail elements keep (0, 1)
-    float mm[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {1.f, 1.f, 1.f, 1.f};
+    float mm[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (j < nvalid) { mm[j] = mean[ncol + j]; ss[j] = sqrtf(var[ncol + j] + eps); }
+      if (j < nvalid) { mm[j] = mean[ncol + j]; dp[j] = div_plan(sqrtf(var[ncol + j] + eps)); }
     m4 = make_float4(mm[0], mm[1], mm[2], mm[3]);
-    s4 = make_float4(ss[0], ss[1], ss[2], ss[3]);
   }
   // pad columns [O+A, ld_sa) of x_sa / xn_sa and [O, ld_o) of xn_obs: lanes take one 16-B zero store each
   // (scalar, <= 31 per matrix: ld - cols < 32 + 3; pads are a few dozen bytes per row)
@@ -313,8 +373,9 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
       const int64_t r = r0 + i;
       if (r >= b) break;
       float4 x = v[i];
-      if (do_norm) {
-        x.x = (x.x - m4.x) / s4.x; x.y = (x.y - m4.y) / s4.y; x.z = (x.z - m4.z) / s4.z; x.w = (x.w - m4.w) / s4.w;
+      if (do_norm) {   // (x - mean) / sd: IEEE-exact quotient through the column's reciprocal
+        x.x = div_exact(x.x - m4.x, dp[0]); x.y = div_exact(x.y - m4.y, dp[1]);
+        x.z = div_exact(x.z - m4.z, dp[2]); x.w = div_exact(x.w - m4.w, dp[3]);
         if (clamp5) {
           x.x = fminf(fmaxf(x.x, -5.f), 5.f); x.y = fminf(fmaxf(x.y, -5.f), 5.f);
           x.z = fminf(fmaxf(x.z, -5.f), 5.f); x.w = fminf(fmaxf(x.w, -5.f), 5.f);
@@ -363,10 +424,11 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
 template <bool HAS_NORM>
 static void launch_gather_fused(int nchunk, unsigned blocks, hipStream_t st, const float* records, RecLayout L, int64_t capacity,
                                 const int64_t* idx, int64_t b, const float* mean, const float* var, float eps, int clamp5,
-                                float* x_sa, int64_t ld_sa, float* xn_sa, float* xn_obs, int64_t ld_o, float* rew, float* done) {
+                                float* x_sa, int64_t ld_sa, float* xn_sa, float* xn_obs, int64_t ld_o, float* rew, float* done,
+                                int write_pads) {
 #define PQLK_GF(R, CH)                                                                                                   \
   hipLaunchKernelGGL((k_replay_gather_fused<HAS_NORM, R, CH>), dim3(blocks), dim3(256), 0, st, records, L, capacity, idx, b, \
-                     mean, var, eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done)
+                     mean, var, eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done, write_pads)
   if (nchunk <= 64) PQLK_GF(4, 1);
   else if (nchunk <= 128) PQLK_GF(2, 2);
   else if (nchunk <= 256) PQLK_GF(1, 4);
@@ -375,9 +437,11 @@ static void launch_gather_fused(int nchunk, unsigned blocks, hipStream_t st, con
 }
 
 extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t* idx, int64_t b, const float* mean,
-                                        const float* var, float eps, int clamp5, float* x_sa, int64_t ld_sa,
+                                        const float* var, float eps, int flags, float* x_sa, int64_t ld_sa,
                                         float* xn_sa, float* xn_obs, int64_t ld_o, float* rew, float* done,
                                         pqlk_stream_t stream) {
+  const int clamp5 = flags & PQLK_GATHER_CLAMP5;
+  const int write_pads = ((flags & PQLK_GATHER_PADS_ZERO) || g_gather_nopad) ? 0 : 1;
   PQLK_REQUIRE(ring && ring->records && idx, PQLK_E_NULL);
   PQLK_REQUIRE(ring->obs_dim > 0 && ring->capacity > 0 && b >= 0, PQLK_E_SHAPE);
   RecLayout L = rec_layout(ring->obs_dim, ring->act_dim);
@@ -399,13 +463,15 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
   if (fast) {
     // rows in flight per wave: 2 up to 16 Ki rows (more waves, shorter dependent idx -> row chain: 9.3 vs 10.5 us at 8192),
     // 4 beyond (same time at 32 Ki rows, fewer blocks)
-    int R = b <= 16384 ? 2 : 4;
+    // 2 rows in flight per wave, at most 16 resident waves per CU (1024 blocks): beyond that the grid-stride loop takes
+    // further trips.  Measured at cfg 5 (32768 rows x 1 KiB): 16 waves/CU x 2 rows 20.8 us, 32 x 4 (one trip each) 24.6 us,
+    // 8 x 2 28 us, 16 x 8 31 us; at cfg 2 (8192 rows) 2 rows per wave 7.4 us vs 8.4 (4) and 9.4 (1)
+    int R = 2;
     if (g_gather_R) R = g_gather_R;
     int64_t fb = (b + 4 * R - 1) / (4 * R);
-    if (fb > 2048) fb = 2048;
-    if (g_gather_waves_per_cu) { const int64_t cap = 256 * (int64_t)g_gather_waves_per_cu / 4; if (fb > cap) fb = cap; }
+    const int wpc = g_gather_waves_per_cu ? g_gather_waves_per_cu : 16;
+    if (fb > 256 * (int64_t)wpc / 4) fb = 256 * (int64_t)wpc / 4;
     const dim3 g((unsigned)fb), t(256);
-    const int write_pads = g_gather_nopad ? 0 : 1;
 #define PQLK_GATHER_FAST(NORM, RR) \
     hipLaunchKernelGGL((k_replay_gather_fast<NORM, RR>), g, t, 0, pqlk_s(stream), ring->records, L, ring->capacity, idx, b, mean, var, \
                        eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done, write_pads)
@@ -420,10 +486,10 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
   }
   if (mean)
     launch_gather_fused<true>(nchunk, (unsigned)blocks, pqlk_s(stream), ring->records, L, ring->capacity, idx, b, mean, var, eps,
-                              clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done);
+                              clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done, write_pads);
   else
     launch_gather_fused<false>(nchunk, (unsigned)blocks, pqlk_s(stream), ring->records, L, ring->capacity, idx, b, mean, var, eps,
-                               clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done);
+                               clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done, write_pads);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }
