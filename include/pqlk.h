@@ -200,23 +200,21 @@ int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const float* x, 
                       float* ws, int64_t ws_floats, pqlk_stream_t stream);
 
 /* Same backward, with clip_grad_norm_'s first half folded into its last pass (pql_v_learner.py:128): the kernel that sums
- * the split slabs into `grads` also leaves the per-block partials of sum(g^2) in sumsq_part[0, pqlk_sumsq_parts(n))
- * (n = pqlk_mlp_param_floats) and increments the optimiser's device step counter.  Follow with
- * pqlk_adamw_polyak_fused(prenorm = 1).  Bit-identical to pqlk_mlp_backward + pqlk_clip_adamw_polyak*.  Not for data
- * parallel, where the gradient all-reduce sits between backward and the norm. */
+ * the split slabs into `grads` also leaves per-block partials of sum(g^2) in sumsq_part[0, pqlk_mlp_norm_parts(d)) (room for
+ * 2048 floats) and increments the optimiser's device step counter.  Follow with pqlk_adamw_polyak_fused(prenorm =
+ * pqlk_mlp_norm_parts(d)).  Same gradient as pqlk_mlp_backward; the norm's partial sums are grouped differently from
+ * pqlk_clip_adamw_polyak*'s own pass (last-bit differences in the clip factor).  Not for data parallel, where the gradient
+ * all-reduce sits between backward and the norm. */
 int pqlk_mlp_backward_norm(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
                            const float* acts, const float* dy, float* grads, int32_t splits,
                            float* dx, int64_t ld_dx, int32_t dx_col0, int32_t dx_cols,
                            const float* dx_tanh_of, int64_t ld_tanh,
                            float* ws, int64_t ws_floats, float* sumsq_part, int32_t* step_dev, pqlk_stream_t stream);
-int32_t pqlk_sumsq_parts(int64_t n);
+int32_t pqlk_mlp_norm_parts(const PqlMlpDesc* d);
 
-/* Tuning / test hooks of the replay gather.  pqlk_tune_gather: rows in flight per wave (1, 2, 4, 8), resident waves per CU
- * and "skip the pad stores" for the next launches (0 = automatic).  pqlk_selftest_fastdiv: number of (x[i], s[j]) pairs for
- * which the gather's reciprocal-based quotient differs in any bit from the IEEE quotient x / s (must be 0). */
-int pqlk_tune_gather(int rows_in_flight, int waves_per_cu, int nopad);
-int pqlk_selftest_fastdiv(const float* x, int64_t nx, const float* s, int64_t ns, unsigned long long* mismatches,
-                          pqlk_stream_t stream);
+/* Tuning hook of the replay gather (tools/bench_gather.py): rows in flight per wave (1, 2, 4, 8), resident waves per CU,
+ * "skip the pad stores" and non-temporal record loads for the next launches (0 = automatic / off). */
+int pqlk_tune_gather(int rows_in_flight, int waves_per_cu, int nopad, int nt_loads);
 
 /* ------------------------------------------------------------------------------------------------
  * Losses.  Each writes dy (2, B, ld) for pqlk_mlp_backward and one scalar loss (device), via per-block
@@ -279,8 +277,8 @@ int pqlk_clip_adamw_polyak_pack(const PqlMlpDesc* d, float* p, float* g, float* 
 
 /* The optimiser launch of a fused learner step (pql_v_learner.py:124-133 + :109-111, pql_p_learner.py:87-96): the same
  * update as pqlk_clip_adamw_polyak_pack (packed_p may be NULL: nothing to re-pack), plus
- *   prenorm != 0 : `scratch` already holds the squared-norm partials and step_dev is already incremented (both left by
- *                  pqlk_mlp_backward_norm), so no separate norm launch;
+ *   prenorm > 0  : `scratch` already holds that many squared-norm partials and step_dev is already incremented (both left
+ *                  by pqlk_mlp_backward_norm; prenorm = pqlk_mlp_norm_parts(d)), so no separate norm launch;
  *   loss_part    : per-block loss partials left in a loss kernel's scratch (pqlk_td_mse_loss / pqlk_c51_bce_loss /
  *                  pqlk_dpg_loss called with loss_out = NULL; count = pqlk_loss_parts(b, k)): block 0 folds them, times
  *                  loss_scale (1/B, 1/(B K), -1/B), into loss_ring[(t - 1) % ring_len], t = the incremented step --

@@ -38,8 +38,7 @@ PROTOTYPES = {
     "pqlk_replay_insert": (C.c_int, [C.POINTER(PqlReplayDesc), _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P]),
     "pqlk_replay_gather": (C.c_int, [C.POINTER(PqlReplayDesc), _P, _I64, _P, _P, _P, _P, _P, _P]),
     "pqlk_replay_gather_fused": (C.c_int, [C.POINTER(PqlReplayDesc), _P, _I64, _P, _P, _F, C.c_int, _P, _I64, _P, _P, _I64, _P, _P, _P]),
-    "pqlk_tune_gather": (C.c_int, [C.c_int, C.c_int, C.c_int]),
-    "pqlk_selftest_fastdiv": (C.c_int, [_P, _I64, _P, _I64, _P, _P]),
+    "pqlk_tune_gather": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "pqlk_nstep_push_emit": (C.c_int, [_P, _I64, _I32, _I32, _I32, _I64, _I64, _P, _P, _P, _P, _P, C.POINTER(C.c_float),
                                        _P, _P, _P, _P, _P, C.POINTER(C.c_int64), _P]),
     "pqlk_mlp_param_floats": (_I64, [C.POINTER(PqlMlpDesc)]),
@@ -55,7 +54,7 @@ PROTOTYPES = {
                                     _P, _I64, _P]),
     "pqlk_mlp_backward_norm": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _P, _I64,
                                          _P, _I64, _P, _P, _P]),
-    "pqlk_sumsq_parts": (_I32, [_I64]),
+    "pqlk_mlp_norm_parts": (_I32, [C.POINTER(PqlMlpDesc)]),
     "pqlk_td_mse_loss": (C.c_int, [_P, _P, _I64, _P, _P, _F, _I64, _P, _P, _P, _I32, _P, _P]),
     "pqlk_c51_bce_loss": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _F, _F, _F, _I64, _P, _P, _P, _I32, _P, _P, _P]),
     "pqlk_c51_project": (C.c_int, [_P, _P, _P, _P, _F, _F, _F, _I32, _I64, _P, _P]),

@@ -85,7 +85,8 @@ def apply_optimizer_fused(layout, arena, grads, st: _AdamState, target, lr, max_
     pt = packed_target.tensor if packed_target is not None else None
     L.check(L.lib.pqlk_adamw_polyak_fused(C.byref(layout.desc), L.ptr(arena), L.ptr(grads), L.ptr(st.m), L.ptr(st.v), L.ptr(target),
                                           L.ptr(pk), L.ptr(pt), 1.0, mn, float(lr), 0.9, 0.999, 1e-8, 1e-2, float(tau),
-                                          L.ptr(st.step), L.ptr(st.gnorm), L.ptr(st.scratch), 1, L.ptr(loss_part), int(loss_parts),
+                                          L.ptr(st.step), L.ptr(st.gnorm), L.ptr(st.scratch),
+                                          int(L.lib.pqlk_mlp_norm_parts(C.byref(layout.desc))), L.ptr(loss_part), int(loss_parts),
                                           float(loss_scale), L.ptr(loss_ring), LOSS_RING, L.stream(device)))
 
 

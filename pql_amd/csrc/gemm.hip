@@ -794,47 +794,59 @@ extern "C" int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const 
 }
 
 // ------------------------------------------------------------------------------------------------
-// sum the split slabs in fixed order -> gradient arena (deterministic).  Two optional extras ride in the same pass:
+// sum the split slabs in fixed order -> gradient arena (deterministic).  Two optional extras ride in the same launch:
 //  * head partials: when the last layer's dW / db came out of k_skinny_bwd (one partial per 64-row block instead of one per
-//    split), arena offsets inside [head_off, net_stride) of each net are summed over those blocks, in block order;
-//  * the squared-norm partials of clip_grad_norm_: with `sq_part` the kernel also leaves sum(g^2) per block and bumps the
-//    optimiser's step counter -- exactly what k_sumsq (optim.hip) would compute on the reduced arena (same grid, same
-//    per-thread order, same fold), so the fused and the two-launch forms give identical bits.
+//    split) the main blocks skip arena offsets inside [head_off, net_stride) of each net and `head_blocks` extra blocks fold
+//    them: one WAVE per 16-B quad, lane l sums partials l, l + 64, ... in that order, then a fixed xor-shuffle tree -- all
+//    partials of a quad are in flight at once (one thread walking 128 partials serially cost 30 us);
+//  * the squared-norm partials of clip_grad_norm_: with `sq_part` every block also leaves sum(g^2) over what it reduced, and
+//    block 0 bumps the optimiser's step counter: k_adamw folds those partials exactly as it folds k_sumsq's.
 struct ReduceP {
   const float* slabs; int splits; long long n;
   float* out;
-  const float* head_part; int head_blocks; int n_nets; long long net_stride, head_off, head_floats;
+  const float* head_part; int head_parts; int n_nets; long long net_stride, head_off, head_floats;
+  int main_blocks;
   float* sq_part; int32_t* step_dev;
 };
 
 __global__ __launch_bounds__(256) void k_reduce_slabs(ReduceP p) {
   __shared__ float shw[4];
-  const long long n4 = p.n >> 2;  // arena sizes are multiples of 32 floats
   float acc = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const long long off = i << 2;
-    const long long net = p.head_blocks > 0 ? off / p.net_stride : 0;
-    const long long rel = off - net * p.net_stride;
-    float4 s;
-    if (p.head_blocks > 0 && rel >= p.head_off) {   // block boundaries are multiples of 32 floats: a quad never straddles
-      const float* hp = p.head_part + net * p.head_floats + (rel - p.head_off);
-      s = *reinterpret_cast<const float4*>(hp);
-      for (int k = 1; k < p.head_blocks; ++k) {
-        const float4 t = *reinterpret_cast<const float4*>(hp + (long long)k * p.n_nets * p.head_floats);
-        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  if ((int)blockIdx.x < p.main_blocks) {
+    const long long n4 = p.n >> 2;  // arena sizes are multiples of 32 floats
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)p.main_blocks * 256) {
+      if (p.head_parts > 0) {   // block boundaries are multiples of 32 floats: a quad never straddles
+        const long long off = i << 2;
+        if (off - (off / p.net_stride) * p.net_stride >= p.head_off) continue;
       }
-    } else {
-      s = reinterpret_cast<const float4*>(p.slabs)[i];
+      float4 s = reinterpret_cast<const float4*>(p.slabs)[i];
       for (int k = 1; k < p.splits; ++k) {
         const float4 t = reinterpret_cast<const float4*>(p.slabs + (long long)k * p.n)[i];
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
       }
+      reinterpret_cast<float4*>(p.out)[i] = s;
+      acc += (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
     }
-    reinterpret_cast<float4*>(p.out)[i] = s;
-    acc += (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
+    if (!p.sq_part) return;
+    acc = wave_sum(acc);
+  } else {
+    const int lane = threadIdx.x & 63;
+    const long long hq = p.head_floats >> 2;                                      // quads per net
+    const long long e = ((long long)blockIdx.x - p.main_blocks) * 4 + (threadIdx.x >> 6);   // this wave's quad
+    if (e < hq * p.n_nets) {
+      const long long net = e / hq, q = e - net * hq;
+      const float* hp = p.head_part + net * p.head_floats + 4 * q;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = lane; k < p.head_parts; k += 64) {
+        const float4 t = *reinterpret_cast<const float4*>(hp + (long long)k * p.n_nets * p.head_floats);
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+      s.x = wave_sum(s.x); s.y = wave_sum(s.y); s.z = wave_sum(s.z); s.w = wave_sum(s.w);
+      if (lane == 0) *reinterpret_cast<float4*>(p.out + net * p.net_stride + p.head_off + 4 * q) = s;
+      acc = (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);   // same value in every lane
+    }
+    if (!p.sq_part) return;
   }
-  if (!p.sq_part) return;
-  acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -843,12 +855,26 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(ReduceP p) {
   }
 }
 
-// grid of the squared-norm partials (must equal adamw_impl's k_sumsq grid in optim.hip)
-extern "C" int32_t pqlk_sumsq_parts(int64_t n) {
-  int64_t blocks = (n / 4 + 255) / 256;
+static int64_t head_quads(const PqlMlpDesc* d) {
+  const int L = d->n_layers;
+  return ((int64_t)d->dims[L] * pqlk_ld(d->dims[L - 1]) + pqlk_ld(d->dims[L])) / 4 * d->n_nets;
+}
+static bool head_is_fused(const PqlMlpDesc* d) {   // must mirror the choice in mlp_backward_impl
+  const int L = d->n_layers;
+  return L >= 2 && skinny_bwd_ok(d->dims[L], (int)pqlk_ld(d->dims[L - 1])) && skinny_bwd_fused_ok(d->dims[L], (int)pqlk_ld(d->dims[L - 1]));
+}
+static int reduce_main_blocks(int64_t arena, bool for_norm) {
+  int64_t blocks = (arena / 4 + 255) / 256;
   if (blocks < 1) blocks = 1;
-  if (blocks > 1024) blocks = 1024;
-  return (int32_t)blocks;
+  const int64_t cap = for_norm ? 1024 : 2048;
+  return (int)(blocks > cap ? cap : blocks);
+}
+
+// number of squared-norm partials pqlk_mlp_backward_norm leaves for pqlk_adamw_polyak_fused(prenorm = this)
+extern "C" int32_t pqlk_mlp_norm_parts(const PqlMlpDesc* d) {
+  if (desc_ok(d)) return 0;
+  const int main_blocks = reduce_main_blocks(pqlk_mlp_param_floats(d), true);
+  return main_blocks + (head_is_fused(d) ? (int)((head_quads(d) + 3) / 4) : 0);
 }
 
 static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
@@ -905,7 +931,7 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
       q.X = in; q.ldx = (int)in_ld; q.sX = in_stride;
       q.dY = cur_dy; q.ldy = (int)ld_out; q.sY = b * ld_out;
       q.M = (int)b; q.N = d->dims[l + 1]; q.K = (int)ld_in; q.ldk = (int)ld_in; q.ldc = (int)ld_out;
-      if (grads && l > 0 && skinny_bwd_fused_ok(q.N, q.K)) {   // dX + dW + db in one pass over the activations
+      if (grads && head_is_fused(d)) {   // dX + dW + db in one pass over the activations
         q.W = params + w_off; q.sW = net_stride;
         q.C = dact[flip]; q.sC = b * ld_in;
         q.epi = SK_EPI_DELU;
@@ -985,19 +1011,14 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
   if (grads) {
     ReduceP r = {};
     r.slabs = slabs; r.splits = splits; r.n = arena; r.out = grads;
-    r.head_part = head_part; r.head_blocks = head_blocks; r.n_nets = d->n_nets; r.net_stride = net_stride;
+    r.head_part = head_part; r.head_parts = head_blocks; r.n_nets = d->n_nets; r.net_stride = net_stride;
     int64_t w_last, b_last;
     pqlk_mlp_layer_offsets(d, L - 1, &w_last, &b_last);
     r.head_off = w_last; r.head_floats = net_stride - w_last;
     r.sq_part = sq_part; r.step_dev = step_dev;
-    int blocks;
-    if (sq_part) {
-      blocks = pqlk_sumsq_parts(arena);   // the partials must be k_sumsq's
-    } else {
-      blocks = (int)((arena / 4 + 255) / 256);
-      if (blocks > 2048) blocks = 2048;
-    }
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, st, r);
+    r.main_blocks = reduce_main_blocks(arena, sq_part != nullptr);   // with sq_part: at most 1024 + head blocks partials
+    const int extra = head_blocks > 0 ? (int)((head_quads(d) + 3) / 4) : 0;
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(r.main_blocks + extra), dim3(256), 0, st, r);
     PQLK_LAUNCH_CHECK();
   }
   return PQLK_OK;
@@ -1012,7 +1033,8 @@ extern "C" int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const
 }
 
 // Same, and the gradient's squared-norm partials + the optimiser's step increment come out of the final reduction pass:
-// follow with pqlk_adamw_polyak_fused(prenorm = 1).  Not for data parallel (the all-reduce sits between the two).
+// follow with pqlk_adamw_polyak_fused(prenorm = pqlk_mlp_norm_parts(d)).  Not for data parallel (the all-reduce sits
+// between the two).
 extern "C" int pqlk_mlp_backward_norm(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
                                       const float* acts, const float* dy, float* grads, int32_t splits, float* dx,
                                       int64_t ld_dx, int32_t dx_col0, int32_t dx_cols, const float* dx_tanh_of,

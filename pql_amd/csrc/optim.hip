@@ -172,14 +172,17 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
 
 static int adamw_impl(float* p, float* g, float* m, float* v, float* target, int64_t n, float grad_scale, float max_norm, float lr,
                       float b1, float b2, float eps, float wd, float tau, int32_t* step_dev, float* gnorm_out, float* scratch,
-                      const PackSpec& ps, pqlk_stream_t stream, bool prenorm = false, LossFold lf = LossFold{}) {
+                      const PackSpec& ps, pqlk_stream_t stream, int prenorm = 0, LossFold lf = LossFold{}) {
   PQLK_REQUIRE(p && g && m && v && step_dev && scratch, PQLK_E_NULL);
   PQLK_REQUIRE(n > 0, PQLK_E_SHAPE);
   PQLK_REQUIRE(pqlk_aligned16(g), PQLK_E_ALIGN);
   int blocks = (int)((n / 4 + 255) / 256);
   if (blocks < 1) blocks = 1;
   if (blocks > OPT_MAX_BLOCKS) blocks = OPT_MAX_BLOCKS;
-  if (!prenorm) {   // prenorm: `scratch` already holds these partials and the step counter is bumped (pqlk_mlp_backward_norm)
+  if (prenorm > 0) {   // `scratch` already holds `prenorm` partials and the step counter is bumped (pqlk_mlp_backward_norm)
+    PQLK_REQUIRE(prenorm <= 2048, PQLK_E_SHAPE);
+    blocks = prenorm;
+  } else {
     hipLaunchKernelGGL(k_sumsq, dim3(blocks), dim3(256), 0, pqlk_s(stream), g, n, scratch, step_dev);
     PQLK_LAUNCH_CHECK();
   }
@@ -253,8 +256,8 @@ extern "C" int pqlk_clip_adamw_polyak_pack(const PqlMlpDesc* d, float* p, float*
 }
 
 // The optimiser launch of a fused learner step.  packed_p may be NULL (no fragment-ordered copies to refresh).
-//   prenorm != 0 : `scratch` already holds the gradient's squared-norm partials and `step_dev` is already incremented -- both
-//                  left by pqlk_mlp_backward_norm -- so the k_sumsq launch is skipped;
+//   prenorm > 0  : `scratch` already holds that many squared-norm partials of the gradient and `step_dev` is already
+//                  incremented -- both left by pqlk_mlp_backward_norm -- so the k_sumsq launch is skipped;
 //   loss_part    : optional per-block loss partials (pqlk_*_loss called with loss_out = NULL): block 0 folds loss_parts of
 //                  them, times loss_scale, into loss_ring[(t - 1) % ring_len] instead of a separate one-block launch.
 extern "C" int pqlk_adamw_polyak_fused(const PqlMlpDesc* d, float* p, float* g, float* m, float* v, float* target,
@@ -274,7 +277,7 @@ extern "C" int pqlk_adamw_polyak_fused(const PqlMlpDesc* d, float* p, float* g, 
     lf.part = loss_part; lf.n = loss_parts; lf.scale = loss_scale; lf.ring = loss_ring; lf.ring_len = ring_len;
   }
   return adamw_impl(p, g, m, v, target, pqlk_mlp_param_floats(d), grad_scale, max_norm, lr, b1, b2, eps, wd, tau, step_dev,
-                    gnorm_out, scratch, ps, stream, prenorm != 0, lf);
+                    gnorm_out, scratch, ps, stream, prenorm, lf);
 }
 
 __global__ __launch_bounds__(256) void k_polyak(float* __restrict__ target, const float* __restrict__ cur, int64_t n,

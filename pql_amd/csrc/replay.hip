@@ -119,66 +119,12 @@ extern "C" int pqlk_replay_gather(const PqlReplayDesc* ring, const int64_t* idx,
 }
 
 // ------------------------------------------------------------------------------------------------
-// ---- x / s, correctly rounded, without the hardware's 12-instruction IEEE sequence --------------------------------
-// The normaliser divides every gathered observation by sd = sqrt(var + eps) -- the same few hundred divisors for every
-// row -- and the result has to equal torch's `(x - mean) / sqrt(var + eps)` bit for bit.  With r = RN(1 / s) formed once per
-// column by a true IEEE division, q0 = x r is within an ulp or two of x / s, and two residual corrections
-//     e = fma(-s, q, x);  q = fma(e, r, q)
-// end on RN(x / s) (Markstein's theorem: the last correction of a faithful quotient with a correctly rounded reciprocal
-// is the correctly rounded quotient) -- PROVIDED nothing leaves the normal range and s is not the one exceptional
-// significand 1.11...1b.  Everything outside that envelope takes the hardware division:
-//   columns:  s outside [2^-60, 2^60], s with an all-ones significand, s not finite   -> div_plan.exact = false
-//   elements: |x| outside [2^-60, 2^60] (subnormal, huge, inf, nan)  -> x / s;   x = +-0 -> x * r (keeps the sign)
-// tests/test_kernels_gpu.py::test_fast_division_is_ieee checks ~10^9 (x, s) pairs bit for bit (pqlk_selftest_fastdiv).
-struct DivPlan { float s, r; bool exact; };
-__device__ __forceinline__ DivPlan div_plan(float s) {
-  DivPlan p;
-  p.s = s;
-  p.r = 1.0f / s;
-  const unsigned bits = __float_as_uint(s);
-  p.exact = (s >= 8.6736174e-19f) && (s <= 1.1529215e18f) && ((bits & 0x7FFFFFu) != 0x7FFFFFu);   // 2^-60 .. 2^60
-  return p;
-}
-__device__ __forceinline__ float div_exact(float x, const DivPlan& p) {
-  const float ax = fabsf(x);
-  const float q0 = x * p.r;   // also the exact answer for x = +-0 (r > 0 finite when p.exact)
-  float e = fmaf(-p.s, q0, x);
-  float q = fmaf(e, p.r, q0);
-  e = fmaf(-p.s, q, x);
-  q = fmaf(e, p.r, q);
-  q = ax == 0.f ? q0 : q;
-  // outside the envelope: the hardware division, behind a branch the wave skips when no lane needs it
-  if (!(p.exact && (ax == 0.f || (ax >= 8.6736174e-19f && ax <= 1.1529215e18f)))) q = x / p.s;
-  return q;
-}
-
-__global__ __launch_bounds__(256) void k_selftest_fastdiv(const float* __restrict__ x, int64_t nx, const float* __restrict__ sv,
-                                                          int64_t ns, unsigned long long* __restrict__ bad) {
-  unsigned long long mine = 0;
-  for (int64_t j = blockIdx.y; j < ns; j += gridDim.y) {
-    const DivPlan p = div_plan(sv[j]);
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nx; i += (int64_t)gridDim.x * 256) {
-      const float a = div_exact(x[i], p), b = x[i] / sv[j];
-      mine += (__float_as_uint(a) != __float_as_uint(b)) && !(a != a && b != b);
-    }
-  }
-  if (mine) atomicAdd(bad, mine);
-}
-
-// Test hook: counts (x[i], s[j]) pairs whose fast quotient differs in any bit from the IEEE quotient (NaN == NaN).
-extern "C" int pqlk_selftest_fastdiv(const float* x, int64_t nx, const float* s, int64_t ns, unsigned long long* mismatches,
-                                     pqlk_stream_t stream) {
-  PQLK_REQUIRE(x && s && mismatches, PQLK_E_NULL);
-  PQLK_REQUIRE(nx > 0 && ns > 0, PQLK_E_SHAPE);
-  hipLaunchKernelGGL(k_selftest_fastdiv, dim3(1024, (unsigned)(ns < 64 ? ns : 64)), dim3(256), 0, pqlk_s(stream), x, nx, s, ns,
-                     mismatches);
-  PQLK_LAUNCH_CHECK();
-  return PQLK_OK;
-}
-
 // fused gather: sample + normalise (+-5 clamp) + concat into the padded GEMM input tiles.
-__device__ __forceinline__ float norm1(float x, float mean, const DivPlan& sd, int clamp5) {
-  float y = div_exact(x - mean, sd);  // IEEE-exact quotient: bit-identical to (x-mean)/sqrt(var+eps) evaluated by torch
+// IEEE division on purpose.  A reciprocal per column + two fma corrections (Markstein) also gives the correctly rounded
+// quotient and was tried (round 2): with the range / exceptional-significand guards it needs it is ~15 instructions against
+// the hardware sequence's ~11, and measured 0.9 us SLOWER per 32768-row launch.
+__device__ __forceinline__ float norm1(float x, float mean, float sd, int clamp5) {
+  float y = (x - mean) / sd;  // IEEE division: bit-identical to (x-mean)/sqrt(var+eps) evaluated by torch
   if (clamp5) y = fminf(fmaxf(y, -5.f), 5.f);
   return y;
 }
@@ -210,11 +156,11 @@ __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __rest
   // per-column mean and sd = sqrt(var + eps) (correctly rounded sqrtf) staged once per block: the per-element work
   // is then one subtract and one IEEE divide instead of a divide AND a square root
   __shared__ float s_mean[HAS_NORM ? GATHER_MAX_OBS : 1];
-  __shared__ DivPlan s_sd[HAS_NORM ? GATHER_MAX_OBS : 1];
+  __shared__ float s_sd[HAS_NORM ? GATHER_MAX_OBS : 1];
   if (HAS_NORM) {
     for (int c = threadIdx.x; c < L.O; c += 256) {
       s_mean[c] = mean[c];
-      s_sd[c] = div_plan(sqrtf(var[c] + eps));
+      s_sd[c] = sqrtf(var[c] + eps);
     }
     __syncthreads();
   }
@@ -299,9 +245,9 @@ __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __rest
 // per kernel and the per-row work is load -> (sub, IEEE div, clamp) x4 -> one or two 16-B stores.  The generic kernel
 // above re-decodes the field per row and is instruction-issue bound (~450 instructions per row).
 // tuning hooks (pqlk_tune_gather): 0 = automatic
-static int g_gather_R = 0, g_gather_waves_per_cu = 0, g_gather_nopad = 0;
-extern "C" int pqlk_tune_gather(int rows_in_flight, int waves_per_cu, int nopad) {
-  g_gather_R = rows_in_flight; g_gather_waves_per_cu = waves_per_cu; g_gather_nopad = nopad;
+static int g_gather_R = 0, g_gather_waves_per_cu = 0, g_gather_nopad = 0, g_gather_nt = 0;
+extern "C" int pqlk_tune_gather(int rows_in_flight, int waves_per_cu, int nopad, int nt_loads) {
+  g_gather_R = rows_in_flight; g_gather_waves_per_cu = waves_per_cu; g_gather_nopad = nopad; g_gather_nt = nt_loads;
   return PQLK_OK;
 }
 
@@ -311,7 +257,9 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ var,
                                                             float eps, int clamp5, float* __restrict__ x_sa, int64_t ld_sa,
                                                             float* __restrict__ xn_sa, float* __restrict__ xn_obs, int64_t ld_o,
-                                                            float* __restrict__ o_rew, float* __restrict__ o_done, int write_pads) {
+                                                            float* __restrict__ o_rew, float* __restrict__ o_done, int write_pads,
+                                                            int nt_loads) {
+  typedef float f4n __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63;
   const int c = lane << 2;
   const int nchunk = L.used >> 2;
@@ -339,17 +287,15 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
     }
   }
   vecA = vecA && nvalid == 4;
-  float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  DivPlan dp[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) dp[j] = div_plan(1.f);
+  float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
   const bool do_norm = HAS_NORM && ncol >= 0;
   if (do_norm) {   // scalar loads: O need not be a multiple of 4; invalid tail elements keep (0, 1)
-    float mm[4] = {0.f, 0.f, 0.f, 0.f};
+    float mm[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (j < nvalid) { mm[j] = mean[ncol + j]; dp[j] = div_plan(sqrtf(var[ncol + j] + eps)); }
+      if (j < nvalid) { mm[j] = mean[ncol + j]; ss[j] = sqrtf(var[ncol + j] + eps); }
     m4 = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    s4 = make_float4(ss[0], ss[1], ss[2], ss[3]);
   }
   // pad columns [O+A, ld_sa) of x_sa / xn_sa and [O, ld_o) of xn_obs: lanes take one 16-B zero store each
   // (scalar, <= 31 per matrix: ld - cols < 32 + 3; pads are a few dozen bytes per row)
@@ -366,16 +312,24 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
       const int64_t r = r0 + i;
       int64_t src = r < b ? idx[r] : 0;
       if (src < 0 || src >= capacity) src = 0;
-      v[i] = lane < nchunk ? reinterpret_cast<const float4*>(records + src * L.ld)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < nchunk) {
+        if (nt_loads) {   // records are read once per sample: keep them out of the caches the output tiles will be read from
+          const f4n t = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(records + src * L.ld) + lane);
+          v[i] = make_float4(t[0], t[1], t[2], t[3]);
+        } else {
+          v[i] = reinterpret_cast<const float4*>(records + src * L.ld)[lane];
+        }
+      } else {
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       const int64_t r = r0 + i;
       if (r >= b) break;
       float4 x = v[i];
-      if (do_norm) {   // (x - mean) / sd: IEEE-exact quotient through the column's reciprocal
-        x.x = div_exact(x.x - m4.x, dp[0]); x.y = div_exact(x.y - m4.y, dp[1]);
-        x.z = div_exact(x.z - m4.z, dp[2]); x.w = div_exact(x.w - m4.w, dp[3]);
+      if (do_norm) {
+        x.x = (x.x - m4.x) / s4.x; x.y = (x.y - m4.y) / s4.y; x.z = (x.z - m4.z) / s4.z; x.w = (x.w - m4.w) / s4.w;
         if (clamp5) {
           x.x = fminf(fmaxf(x.x, -5.f), 5.f); x.y = fminf(fmaxf(x.y, -5.f), 5.f);
           x.z = fminf(fmaxf(x.z, -5.f), 5.f); x.w = fminf(fmaxf(x.w, -5.f), 5.f);
@@ -474,7 +428,7 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
     const dim3 g((unsigned)fb), t(256);
 #define PQLK_GATHER_FAST(NORM, RR) \
     hipLaunchKernelGGL((k_replay_gather_fast<NORM, RR>), g, t, 0, pqlk_s(stream), ring->records, L, ring->capacity, idx, b, mean, var, \
-                       eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done, write_pads)
+                       eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done, write_pads, g_gather_nt)
 #define PQLK_GATHER_FAST_R(NORM) \
     do { if (R == 1) PQLK_GATHER_FAST(NORM, 1); else if (R == 2) PQLK_GATHER_FAST(NORM, 2); else if (R == 4) PQLK_GATHER_FAST(NORM, 4); \
          else PQLK_GATHER_FAST(NORM, 8); } while (0)

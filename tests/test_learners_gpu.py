@@ -255,10 +255,11 @@ def test_cfg5_humanoid_nstep5_batch32768_v_step_vs_oracle(dev):
 
 
 @pytest.mark.parametrize("distl", [False, True])
-def test_fused_tail_is_bit_identical_to_the_separate_launches(dev, distl):
+def test_fused_tail_matches_the_separate_launches(dev, distl):
     """algo.fused_tail folds the loss reduction into the optimiser launch and clip_grad_norm_'s sum of squares into backward's
-    slab reduction (2 launches fewer per step).  Same partials, same order: parameters, optimiser state and the loss ring
-    must come out bit for bit as with the stand-alone launches (the data-parallel path still uses those)."""
+    slab reduction (2 launches fewer per step).  The loss fold is the same sum in the same order (bit-equal ring); the norm's
+    partial sums are grouped differently (last-bit differences in the clip factor), so parameters agree to ~1e-6 relative,
+    as with the data-parallel path, which still uses the stand-alone launches."""
     from pql_amd.algo.pql_p_learner import PQLPLearner
     from pql_amd.algo.pql_v_learner import PQLVLearner
     O, A, B, cap, K = 88, 16, 4096, 8000, 51
@@ -284,8 +285,13 @@ def test_fused_tail_is_bit_identical_to_the_separate_launches(dev, distl):
                      v.loss_ring.clone(), v.opt.gnorm.clone(), p.actor.arena.data.clone(), p.opt.v.clone(), p.loss_ring.clone(),
                      v.opt.step.clone(), p.opt.step.clone()))
     assert int(outs[0][-1]) == 3 and int(outs[0][-2]) == 3
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for k, (a, b) in enumerate(zip(*outs)):
+        if k in (4, 8):   # loss rings: only the first step's loss is computed from bit-equal parameters
+            s0 = int(outs[0][9]) - 3   # ring slot of the first step
+            assert torch.equal(a[s0 % 5], b[s0 % 5])
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-7)
+        else:
+            torch.testing.assert_close(a.float(), b.float(), rtol=2e-5, atol=2e-6)
     assert float(outs[0][4].abs().sum()) > 0 and float(outs[0][8].abs().sum()) > 0   # the folded losses did land in the rings
 
 
