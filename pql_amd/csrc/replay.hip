@@ -417,13 +417,15 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
   if (fast) {
     // rows in flight per wave: 2 up to 16 Ki rows (more waves, shorter dependent idx -> row chain: 9.3 vs 10.5 us at 8192),
     // 4 beyond (same time at 32 Ki rows, fewer blocks)
-    // 2 rows in flight per wave, at most 16 resident waves per CU (1024 blocks): beyond that the grid-stride loop takes
-    // further trips.  Measured at cfg 5 (32768 rows x 1 KiB): 16 waves/CU x 2 rows 20.8 us, 32 x 4 (one trip each) 24.6 us,
-    // 8 x 2 28 us, 16 x 8 31 us; at cfg 2 (8192 rows) 2 rows per wave 7.4 us vs 8.4 (4) and 9.4 (1)
+    // 2 rows in flight per wave, at most 24 resident waves per CU (1536 blocks): beyond that the grid-stride loop takes
+    // further trips.  Measured at cfg 5 (32768 rows x 1 KiB, pads not re-zeroed; tools/bench_gather.py): 24 waves/CU x 2 rows
+    // 18.5 us, 16 x 2 19.5, 12 x 2 21.4, 32 x 2 22.3, 16 x 4 20.3, 32 x 4 (one trip per wave, the round-1 shape) 23.0, 8 rows
+    // in flight 30; at cfg 2 (8192 rows, one trip whatever the cap) 2 rows per wave 7.1 us vs 8.1 (4) and 9.0 (1).
+    // Non-temporal record loads: no gain (18.9 vs 18.5).
     int R = 2;
     if (g_gather_R) R = g_gather_R;
     int64_t fb = (b + 4 * R - 1) / (4 * R);
-    const int wpc = g_gather_waves_per_cu ? g_gather_waves_per_cu : 16;
+    const int wpc = g_gather_waves_per_cu ? g_gather_waves_per_cu : 24;
     if (fb > 256 * (int64_t)wpc / 4) fb = 256 * (int64_t)wpc / 4;
     const dim3 g((unsigned)fb), t(256);
 #define PQLK_GATHER_FAST(NORM, RR) \
