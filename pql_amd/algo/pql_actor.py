@@ -98,7 +98,7 @@ class PQLActor:
         if self.noise_scheduler is not None:
             self.noise_scheduler.step()
 
-    def get_actions(self, obs, sample=True):
+    def get_actions(self, obs, sample=True, draw=None):
         """Policy action on rollout-normalised observations (no +-5 clamp on this side, torch_util.py:83-85), plus
         exploration noise: 'mixed' = per-env sigma spread over [std_min, std_max] along the global env axis."""
         x = self.obs_rms.normalize(obs) if self.cfg.algo.obs_norm else obs
@@ -108,9 +108,9 @@ class PQLActor:
         noise = self.cfg.algo.noise
         if noise.type == "mixed":
             return add_mixed_normal_noise(act, std_min=noise.std_min, std_max=noise.std_max, out_bounds=[-1., 1.],
-                                          env_offset=self.env_offset, total_envs=self.total_envs, generator=self.gen)
+                                          env_offset=self.env_offset, total_envs=self.total_envs, generator=self.gen, draw=draw)
         if noise.type == "fixed":
-            return add_normal_noise(act, std=self.get_noise_std(), out_bounds=[-1., 1.], generator=self.gen)
+            return add_normal_noise(act, std=self.get_noise_std(), out_bounds=[-1., 1.], generator=self.gen, draw=draw)
         raise NotImplementedError(noise.type)
 
     @torch.no_grad()
@@ -161,10 +161,12 @@ class PQLActor:
         return sl
 
     @torch.no_grad()
-    def explore_env(self, env, timesteps: int, random: bool):
+    def explore_env(self, env, timesteps: int, random: bool, draws=None):
         """Step the vectorised env `timesteps` times and return `(obs for the P-learner, 5-tuple for the V-learner,
         env steps taken)` -- the contract of pql_actor.py:87-127.  Everything stays on the GPU and nothing synchronises
-        with the host: running statistics, trackers, the n-step window and the hand-off copies are all stream work."""
+        with the host: running statistics, trackers, the n-step window and the hand-off copies are all stream work.
+        `draws`: optional per-step (N, A) samples to use instead of this actor's generator (parity tests): U(0,1) when
+        `random`, N(0,1) otherwise -- the two draws the reference makes (pql_actor.py:101, noise.py:34-35)."""
         algo, n = self.cfg.algo, self.cfg.num_envs
         sl = self._trajectory_slabs(timesteps)
         obs = self.obs
@@ -172,9 +174,11 @@ class PQLActor:
             if self.obs_rms is not None:
                 self.obs_rms.update(obs)
             if random:   # warm-up: U(-1, 1) actions
-                action = torch.rand((n, self.action_dim), device=self.sim_device, generator=self.gen).mul_(2.0).sub_(1.0)
+                u = (torch.rand((n, self.action_dim), device=self.sim_device, generator=self.gen) if draws is None
+                     else draws[t].to(self.sim_device, torch.float32).clone())
+                action = u.mul_(2.0).sub_(1.0)
             else:
-                action = self.get_actions(obs, sample=True)
+                action = self.get_actions(obs, sample=True, draw=None if draws is None else draws[t].to(self.sim_device))
             next_obs, reward, done, info = env.step(action)
             self.update_tracker(reward, done, info)
             if algo.handle_timeout:

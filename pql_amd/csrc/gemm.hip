@@ -581,7 +581,7 @@ static int64_t max_hidden_ld(const PqlMlpDesc* d) {
 static int64_t head_part_floats(const PqlMlpDesc* d, int64_t b) {   // room for k_skinny_bwd's per-block partials
   const int L = d->n_layers;
   const int64_t hf = (int64_t)d->dims[L] * pqlk_ld(d->dims[L - 1]) + pqlk_ld(d->dims[L]);
-  return (int64_t)skinny_bwd_blocks(b) * d->n_nets * hf;
+  return (int64_t)skinny_bwd_blocks(b, d->n_nets) * d->n_nets * hf;
 }
 
 extern "C" int64_t pqlk_mlp_bwd_ws_floats(const PqlMlpDesc* d, int64_t b, int32_t splits) {
@@ -935,7 +935,7 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
         q.W = params + w_off; q.sW = net_stride;
         q.C = dact[flip]; q.sC = b * ld_in;
         q.epi = SK_EPI_DELU;
-        head_blocks = skinny_bwd_blocks(b);
+        head_blocks = skinny_bwd_blocks(b, d->n_nets);
         rc = launch_skinny_bwd(q, d->n_nets, head_part, (long long)(net_stride - w_off), st);
         if (rc) return rc;
         cur_dy = dact[flip];

@@ -276,9 +276,9 @@ __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
 // per wave, SKB_ROWS rows per block so that B = 8192 x 2 nets gives 256 blocks.  Every block leaves its partial
 // (N x ldk weights, then ld(N) biases: the arena layout of the layer) in `part[block][group]`; the slab-reduction kernel
 // folds the blocks in index order (deterministic, no atomics).  NB = compile-time bound on N (register arrays).
-#define SKB_ROWS 64
+#define SKB_ROWS 64   // rows per block when that still gives every CU a block; halved (down to 16) otherwise
 template <int NB, int CH>
-__global__ __launch_bounds__(256) void k_skinny_bwd(SkinnyP p, float* __restrict__ part, long long part_floats) {
+__global__ __launch_bounds__(256) void k_skinny_bwd(SkinnyP p, float* __restrict__ part, long long part_floats, int rows_per_block) {
   extern __shared__ __attribute__((aligned(16))) float sk_lds[];   // W (N, K) | red[3] (N, K) | dbred[4][16]
   const int g = blockIdx.y;
   const int kq = p.K >> 2;
@@ -302,10 +302,10 @@ __global__ __launch_bounds__(256) void k_skinny_bwd(SkinnyP p, float* __restrict
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[n][c] = make_float4(0.f, 0.f, 0.f, 0.f);
   float dbacc = 0.f;   // lane n < N: sum of dY[:, n] over this wave's rows
-  const int m_blk = blockIdx.x * SKB_ROWS;
-  // rows m_blk + wave + 4 j, j = 0..15, taken four at a time: all 4 x CH activation loads and the 4 dY loads of a group
-  // are requested before the first is used
-  for (int j0 = 0; j0 < SKB_ROWS / 4; j0 += 4) {
+  const int m_blk = blockIdx.x * rows_per_block;
+  // rows m_blk + wave + 4 j, j = 0 .. rows_per_block / 4 - 1, taken four at a time: all 4 x CH activation loads and the 4 dY
+  // loads of a group are requested before the first is used
+  for (int j0 = 0; j0 < rows_per_block / 4; j0 += 4) {
     float4 xv[4][CH];
     float dyl[4];
 #pragma unroll
@@ -393,7 +393,13 @@ static inline int skinny_bwd_nb(int n_out) { return n_out == 1 ? 1 : (n_out <= 4
 static inline bool skinny_bwd_fused_ok(int n_out, int k_padded) {
   return n_out <= SKINNY_MAX_N && k_padded <= SKINNY_MAX_K && skinny_bwd_nb(n_out) * skinny_bwd_ch(k_padded) <= 16;
 }
-static inline int skinny_bwd_blocks(int64_t m) { return (int)((m + SKB_ROWS - 1) / SKB_ROWS); }
+// rows per block: 64, halved while the grid would leave CUs without a block (one net at batch 8192: 32 rows -> 256 blocks)
+static inline int skinny_bwd_rows(int64_t m, int groups) {
+  int r = SKB_ROWS;
+  while (r > 16 && ((m + r - 1) / r) * groups < 256) r >>= 1;
+  return r;
+}
+static inline int skinny_bwd_blocks(int64_t m, int groups) { const int r = skinny_bwd_rows(m, groups); return (int)((m + r - 1) / r); }
 
 template <int NB, int CH>
 static int launch_skinny_bwd_t(const SkinnyP& p, int groups, float* part, long long part_floats, hipStream_t st) {
@@ -404,7 +410,8 @@ static int launch_skinny_bwd_t(const SkinnyP& p, int groups, float* part, long l
                                        (4 * 4096 + 64) * (int)sizeof(float));   // N x K <= 16 x 256 floats
     if (e != hipSuccess) return -(int)e;
   }
-  hipLaunchKernelGGL((k_skinny_bwd<NB, CH>), dim3(skinny_bwd_blocks(p.M), groups), dim3(256), sh, st, p, part, part_floats);
+  hipLaunchKernelGGL((k_skinny_bwd<NB, CH>), dim3(skinny_bwd_blocks(p.M, groups), groups), dim3(256), sh, st, p, part, part_floats,
+                     skinny_bwd_rows(p.M, groups));
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }

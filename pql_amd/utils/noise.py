@@ -10,8 +10,9 @@ def _draw(shape, dtype, device, std, generator=None):
 _STD_CACHE = {}
 
 
-def add_normal_noise(x, std, noise_bounds=None, out_bounds=None, generator=None):
-    noise = _draw(x.shape, x.dtype, x.device, std, generator)
+def add_normal_noise(x, std, noise_bounds=None, out_bounds=None, generator=None, draw=None):
+    """`draw`: optional injected N(0,1) sample of x's shape (parity tests); otherwise drawn from `generator`."""
+    noise = _draw(x.shape, x.dtype, x.device, std, generator) if draw is None else draw.to(x.dtype) * std
     if noise_bounds is not None:
         noise = noise.clamp(noise_bounds[0], noise_bounds[1])
     out = x + noise
@@ -19,7 +20,7 @@ def add_normal_noise(x, std, noise_bounds=None, out_bounds=None, generator=None)
 
 
 def add_mixed_normal_noise(x, std_max, std_min, noise_bounds=None, out_bounds=None, env_offset=0, total_envs=None,
-                           generator=None):
+                           generator=None, draw=None):
     """Per-env sigma = linspace(std_min, std_max, N)[env].  env_offset/total_envs let a data-parallel
     rank index the GLOBAL env axis."""
     n = x.shape[0] if total_envs is None else total_envs
@@ -28,7 +29,7 @@ def add_mixed_normal_noise(x, std_max, std_min, noise_bounds=None, out_bounds=No
     if std is None:   # built on the host like the reference (same fp32 values), uploaded ONCE: no per-step H2D sync
         std = torch.linspace(std_min, std_max, n)[env_offset: env_offset + x.shape[0]].to(x.device).unsqueeze(-1)
         _STD_CACHE[key] = std
-    noise = _draw(x.shape, x.dtype, x.device, 1.0, generator) * std
+    noise = (_draw(x.shape, x.dtype, x.device, 1.0, generator) if draw is None else draw.to(x.dtype)) * std
     if noise_bounds is not None:
         noise = noise.clamp(noise_bounds[0], noise_bounds[1])
     out = x + noise

@@ -226,3 +226,104 @@ def test_bench_split2_layout_rehearsed_on_one_card():
     assert cfg["layout"] == "split2" and cfg["ranks"] == 1 and cfg["share_gpu"] is True and line["n_gpus"] == 1
     assert "functional split" in cfg["workload"] and line["value"] > 0
     assert line["roofline"]["frac"] > 0 and line["roofline_gather"]["frac"] > 0
+
+
+# --------------------------------------------------------------------------- a24: the composed rollout
+class _RecordingEnv:
+    """The env is an INPUT of the rollout for both sides: record what the product's env returned so the oracle can be
+    driven by the very same transitions (the synthetic env's Box-Muller differs in the last bit between GPU and CPU libm)."""
+
+    def __init__(self, env):
+        self.env, self.log, self.first_obs = env, [], None
+        self.observation_space, self.action_space = env.observation_space, env.action_space
+        self.max_episode_length, self.num_envs = env.max_episode_length, env.num_envs
+
+    def reset(self):
+        self.first_obs = self.env.reset()
+        return self.first_obs
+
+    def step(self, action):
+        out = self.env.step(action)
+        self.log.append((action.clone(), out[0].clone(), out[1].clone(), out[2].clone()))
+        return out
+
+
+def test_composed_rollout_explore_env_vs_oracle():
+    """SURVEY 8(a) row a24, pql/algo/pql_actor.py:87-147 as ONE composition: per env step RunningMeanStd.update(obs) ->
+    un-clamped normalise -> policy -> mixed per-env noise (or U(-1,1) in the warm-up) -> env.step -> episode trackers ->
+    handle_timeout; then reward scale -> n-step assembly -> the (obs, 5-tuple, steps) hand-off.  Warm-up T = 32, then three
+    T = 1 calls, with the noise draws injected.  Bars: emitted n-step rows bit-exact, actions 1e-5, statistics 1e-6,
+    tracker windows equal to the reference's deque."""
+    from collections import deque
+    import detdata as dd
+    from oracle import pql_ref_cpu as ref
+    from pql_amd.algo.pql_actor import PQLActor
+    from pql_amd.envs.synthetic import create_task_env
+    from pql_amd.models.mlp import TanhMLPPolicy
+    from pql_amd.utils.cfg import load_cfg
+    dev = torch.device("cuda:0")
+    N, O, A, n = 96, 8, 2, 3
+    cfg = load_cfg(["task=Toy", "task.episode_length=6", f"num_envs={N}", "algo.tracker_len=20", "algo.v_learner_gpu=0",
+                    "algo.p_learner_gpu=0", "algo.num_gpus=1", "sim_device=cuda:0", "device=cuda:0", f"algo.nstep={n}"])
+    cfg.algo.reward_scale = 0.01
+    env = _RecordingEnv(create_task_env(cfg))
+    actor = PQLActor(env, cfg)
+    ast = dd.mlp_state(O, A, 17)
+    pol = TanhMLPPolicy((O,), A).to(dev)
+    pol.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in ast.items()})
+    actor.set_actor(pol)
+    actor.reset_agent()
+
+    # ---- oracle state
+    apar = ref.params_from_state(ast)
+    rms, ns = ref.RunningMeanStdRef((O,)), ref.NStepRef(O, A, N, n)
+    ret_win, len_win = deque([0.0] * 20, maxlen=20), deque([0.0] * 20, maxlen=20)
+    cur_ret, cur_len = torch.zeros(N), torch.zeros(N)
+    g = torch.Generator().manual_seed(3)
+    obs = env.first_obs.cpu()
+    cursor = 0
+
+    def oracle_call(T, random, draws):
+        nonlocal obs, cursor, cur_ret, cur_len
+        sl = [torch.zeros((N, T, O)), torch.zeros((N, T, A)), torch.zeros((N, T, 1)), torch.zeros((N, T, O)), torch.zeros((N, T, 1))]
+        for t in range(T):
+            rms.update(obs)                                                                    # :98-99
+            if random:
+                act = draws[t] * 2.0 - 1.0                                                     # :100-102
+            else:
+                act = ref.mixed_noise_ref(ref.actor_forward_ref(apar, ref.normalize_ref(obs, rms.states(), clamp=False)),
+                                          draws[t], float(cfg.algo.noise.std_min), float(cfg.algo.noise.std_max))   # :69-85
+            logged_act, nobs, rew, done = (x.cpu() for x in env.log[cursor]); cursor += 1
+            torch.testing.assert_close(logged_act, act, rtol=0, atol=1e-5)
+            done = done.float()
+            cur_ret += rew; cur_len += 1                                                       # :129-135
+            fin = done.bool()
+            ret_win.extend(cur_ret[fin].tolist()); len_win.extend(cur_len[fin].tolist())
+            cur_ret[fin] = 0; cur_len[fin] = 0
+            sl[0][:, t] = obs; sl[1][:, t] = logged_act; sl[2][:, t, 0] = rew; sl[3][:, t] = nobs; sl[4][:, t, 0] = done
+            obs = nobs
+        sl[2] = sl[2] * 0.01                                                                    # :116
+        return ns.add(*sl)                                                                      # :118
+
+    def check(T, random):
+        draws = [torch.rand((N, A), generator=g) if random else torch.randn((N, A), generator=g) for _ in range(T)]
+        p_data, v_data, steps = actor.explore_env(env, T, random=random, draws=[d.to(dev) for d in draws])
+        want = oracle_call(T, random, draws)
+        torch.cuda.synchronize()
+        assert steps == T * N and len(v_data) == 5
+        for name, got, exp in zip(("obs", "action", "reward", "next_obs", "done"), v_data, want):
+            assert got.shape == exp.shape and got.dtype == torch.float32, name
+            assert torch.equal(got.cpu(), exp), name                  # emitted n-step rows: bit-exact (time-major order included)
+        assert torch.equal(p_data.cpu(), want[0])
+        m, v, eps = actor.obs_rms.get_states()
+        torch.testing.assert_close(m.cpu(), rms.mean, rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(v.cpu(), rms.var, rtol=1e-5, atol=1e-6)
+        assert eps == rms.eps and abs(actor.obs_rms.count - rms.count) < 1e-6 * rms.count
+        assert actor.return_tracker.mean() == pytest.approx(float(np.mean(ret_win)), rel=1e-5, abs=1e-7)
+        assert actor.step_tracker.mean() == pytest.approx(float(np.mean(len_win)), rel=1e-6)
+        assert torch.equal(actor.obs.cpu(), obs)
+
+    check(32, True)          # warm-up (train_pql.py:57-59): T - n + 1 = 30 emitted blocks of N rows
+    for _ in range(3):
+        check(1, False)      # steady state: one block of N rows per call
+    assert sum(x != 0 for x in len_win) > 10   # episodes did finish (mean length 6): the trackers were exercised
