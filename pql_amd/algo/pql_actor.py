@@ -178,7 +178,8 @@ class PQLActor:
                      else draws[t].to(self.sim_device, torch.float32).clone())
                 action = u.mul_(2.0).sub_(1.0)
             else:
-                action = self.get_actions(obs, sample=True, draw=None if draws is None else draws[t].to(self.sim_device))
+                action = (self.get_actions(obs, sample=True) if draws is None
+                          else self.get_actions(obs, sample=True, draw=draws[t].to(self.sim_device)))
             next_obs, reward, done, info = env.step(action)
             self.update_tracker(reward, done, info)
             if algo.handle_timeout:
