@@ -1,13 +1,17 @@
 #!/bin/bash
-# usage: tools/profile_bench.sh <tag>   (run on the GPU box from the repo root)
-# rocprofv3 kernel-trace summaries of bench.py: the headline schedule, and the V-learner / P-learner alone on ONE stream
-# (--no-streams) so every kernel's average is free of cross-stream contention.  Outputs land in gpurun_out/<tag>/; copy the
-# *_kernel_stats.csv files you want judged into profiles/.
+# usage: tools/profile_bench.sh <tag> [full]      (run on the GPU box from the repo root)
+# rocprofv3 kernel-trace summaries of bench.py:
+#   sched   the headline 1:4:8 schedule, three HIP streams (per-kernel averages include cross-stream contention)
+#   v_only  the V-learner alone on ONE stream (--no-streams): every kernel's average is contention-free
+#   p_only  the P-learner alone on ONE stream
+# and, with `full`, the two PMC passes (FETCH_SIZE / WRITE_SIZE, kernel-trace only, separate runs) reduced by
+# tools/pmc_traffic.py, plus un-profiled bench lines for the other BASELINE shapes.
+# Outputs land in gpurun_out/<tag>/; copy what should be judged into profiles/.
 set -e
 TAG=${1:-prof}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-cd /tmp 2>/dev/null && export TMPDIR=/tmp && cd - >/dev/null
+export TMPDIR=/tmp
 run() {   # name, bench flags...
   local name=$1; shift
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python3 bench.py --no-cpu-baseline --repeat 1 "$@" \
@@ -16,6 +20,24 @@ run() {   # name, bench flags...
   cp "$f" $OUT/${name}_kernel_stats.csv
   rm -rf $OUT/$name
 }
+pmc() {   # counter name
+  local c=$1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python3 bench.py --steps 48 --warmup 16 \
+      --no-cpu-baseline --no-streams --v-only --repeat 1 > /dev/null 2> $OUT/pmc_$c.err || { tail -5 $OUT/pmc_$c.err; return 1; }
+  find $OUT/pmc_$c -name "*counter_collection.csv" | head -1
+}
 run sched --steps 400 --warmup 48
 run v_only --steps 200 --warmup 24 --no-streams --v-only
 run p_only --steps 200 --warmup 24 --no-streams --p-only
+if [ "$2" = "full" ]; then
+  F=$(pmc FETCH_SIZE); W=$(pmc WRITE_SIZE)
+  python3 tools/pmc_traffic.py "$F" "$W" $OUT/pmc_traffic.json > /dev/null
+  rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+  python3 bench.py --steps 800 --warmup 96 > $OUT/bench.json 2> $OUT/bench.err
+  python3 bench.py --no-cpu-baseline --hidden 512,256,128 > $OUT/bench_hidden_ref.json 2>/dev/null
+  python3 bench.py --no-cpu-baseline --task ShadowHand --num-envs 16384 --distl --replay 2000000 --hidden 512,256,128 > $OUT/bench_cfg4.json 2>/dev/null
+  python3 bench.py --no-cpu-baseline --task Humanoid --batch 32768 --nstep 5 --replay 5000000 --hidden 512,256,128 --steps 200 > $OUT/bench_cfg5.json 2>/dev/null
+  python3 bench.py --no-cpu-baseline --gpus 2 --layout split2 --share-gpu > $OUT/bench_split2_one_card.json 2>/dev/null
+  python3 bench.py --no-cpu-baseline --gpus 2 --backend gloo --share-gpu --steps 100 > $OUT/bench_dp2_gloo_one_card.json 2>/dev/null
+  python3 tools/bench_gather.py cfg2 cfg5 cfg4 > $OUT/gather_sweep.log 2>&1
+fi
