@@ -368,6 +368,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // Accumulator layout after the operand swap (the MFMA computes the TRANSPOSED 32x32 tile): lane (r, h) owns output
   // row `.. + r` and, in register quad q = e>>2, the four consecutive columns `.. + 8q + 4h + (e&3)`: every quad is one
   // 16-B store / load instead of four scalar ones (the epilogue is store-issue bound: 64 -> 16 instructions per tile).
+  //
+  // Full tiles of the backward products (dX with or without ELU', dW slabs) go out through LDS instead: straight from the
+  // accumulators one store instruction touches 32 rows x 32 B (and the ELU' operand comes in the same way), i.e. quarter
+  // lines; staged through the (now idle) pipeline stages, each wave re-reads its 32 x WN patch row by row and one
+  // instruction moves 64 / (WN / 4) whole row segments of WN x 4 B (256 B at WN = 64): full 128-B lines both ways.
+  // The patch is private to the wave (rows wm.., columns wn..), so the two barriers per pass only order LDS reuse.
+  if (MODE != MODE_FWD && EPI != EPI_DTANH_SLICE) {
+    const bool whole = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (MODE == MODE_DW || !p.C2);
+    if (whole) {   // block-uniform
+      constexpr int PLD = WN + 4;            // patch row stride: conflict-free b128 writes (lane rows 4 banks apart) and reads
+      constexpr int LPR = WN / 4;            // lanes per patch row
+      constexpr int RPI = 64 / LPR;          // rows per wave instruction
+      // (launch_gemm sizes the dynamic LDS as max(two pipeline stages, four patches))
+      float* patch = smem + wave * (32 * PLD);
+      const int gq = (MODE == MODE_DX && p.zsum) ? 0 : g0;
+      float* Cw = (MODE == MODE_DW) ? p.C + (long long)g0 * p.sC + (long long)split * p.sSplit : p.C + (long long)gq * p.sC;
+      const float* auxw = (EPI == EPI_DELU && p.aux) ? p.aux + (long long)gq * p.sAux : nullptr;
+      const int prow = lane / LPR, pc4 = lane % LPR;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(patch + r * PLD + 32 * j + 8 * q + 4 * h) =
+                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 32 / RPI; ++it) {
+          const int rr = it * RPI + prow;
+          float4 v = *reinterpret_cast<const float4*>(patch + rr * PLD + 4 * pc4);
+          const long long grow = m0 + wm + 32 * i + rr;
+          const int gcol = n0 + wn + 4 * pc4;
+          if (EPI == EPI_DELU) {
+            const float4 h4 = *reinterpret_cast<const float4*>(auxw + grow * p.ldaux + gcol);
+            v.x = h4.x > 0.f ? v.x : v.x * (h4.x + 1.f);  // ELU'(x) = exp(x) = elu(x) + 1 for x <= 0
+            v.y = h4.y > 0.f ? v.y : v.y * (h4.y + 1.f);
+            v.z = h4.z > 0.f ? v.z : v.z * (h4.z + 1.f);
+            v.w = h4.w > 0.f ? v.w : v.w * (h4.w + 1.f);
+          }
+          *reinterpret_cast<float4*>(Cw + grow * p.ldc + gcol) = v;
+        }
+        if (i + 1 < MI) __syncthreads();
+      }
+      if (MODE == MODE_DW && blockIdx.x == 0 && tid < BM && p.dbias) {
+        float* db = p.dbias + (long long)g0 * p.sBias + (long long)split * p.sSplit;
+        const int row = m0 + tid;
+        if (row < p.ncols_store) db[row] = row < p.M ? dbacc : 0.f;
+      }
+      return;
+    }
+  }
   if (MODE == MODE_DW) {
     float* C = p.C + (long long)g0 * p.sC + (long long)split * p.sSplit;
 #pragma unroll
@@ -474,7 +526,9 @@ template <int MODE, int BM, int BN, int EPI>
 static int launch_gemm(GemmP p, int gz, hipStream_t st) {
   constexpr int KT = PQLK_KT;
   using S = Smem<MODE, BM, BN, KT>;
-  const size_t shmem = (size_t)2 * S::STAGE * sizeof(float);
+  constexpr size_t stage_floats = (size_t)2 * S::STAGE;
+  constexpr size_t patch_floats = (size_t)4 * 32 * (BN / 2 + 4);   // the epilogue's per-wave staging patches
+  const size_t shmem = (stage_floats > patch_floats ? stage_floats : patch_floats) * sizeof(float);
   static PqlkPerDeviceOnce attr_once;
   if (attr_once.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, BM, BN, EPI, KT>),
