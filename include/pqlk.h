@@ -364,6 +364,18 @@ int pqlk_synth_env_step(int64_t n, int32_t obs_dim, int32_t act_dim, uint32_t se
                         float p_done, const float* action, float* next_obs, float* reward, uint8_t* done,
                         pqlk_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-env-step bookkeeping of the rollout in one launch (pql_actor.py:104-114 slab writes, :129-135 update_tracker,
+ * common.py:195-202 handle_timeout): column t of the (N, horizon, .) trajectory slabs <- (obs, action, reward, next_obs,
+ * done * !truncated); cur_return += reward, cur_length += 1; the finished envs' values are appended IN ENV ORDER to the two
+ * moving windows of win_len floats (the last win_len of them when more finish in one step, like deque.extend) behind the
+ * windows' device write pointers, and their accumulators reset.  done / truncated are bytes (truncated may be NULL). */
+int pqlk_rollout_step(int64_t n, int32_t obs_dim, int32_t act_dim, int32_t horizon, int32_t t, const float* obs,
+                      const float* action, const float* next_obs, const float* reward, const uint8_t* done,
+                      const uint8_t* truncated, float* slab_obs, float* slab_act, float* slab_rew, float* slab_nobs,
+                      float* slab_done, float* cur_return, float* cur_length, float* win_return, float* win_length,
+                      int64_t* win_return_ptr, int64_t* win_length_ptr, int32_t win_len, pqlk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

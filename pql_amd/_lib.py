@@ -72,6 +72,7 @@ PROTOTYPES = {
     "pqlk_bn_elu_forward": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P, _P, _F, _I32, _F, _P, _P, _P, _P]),
     "pqlk_bn_elu_backward": (C.c_int, [_P, _P, _P, _I64, _I64, _I32, _P, _P, _P, _F, _P, _P, _P, _P, _P]),
     "pqlk_synth_env_step": (C.c_int, [_I64, _I32, _I32, C.c_uint32, C.c_uint32, C.c_uint32, _F, _P, _P, _P, _P, _P]),
+    "pqlk_rollout_step": (C.c_int, [_I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P]),
     "pqlk_batch_moments": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P, _P]),
 }
 

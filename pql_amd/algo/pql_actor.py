@@ -26,7 +26,7 @@ class DeviceTracker:
     def __init__(self, max_len, device):
         self.max_len = int(max_len)
         self.ring = torch.zeros(self.max_len + 1, device=device)   # last slot = discard bin
-        self.ptr = torch.zeros((), dtype=torch.int64, device=device)
+        self.ptr = torch.zeros(1, dtype=torch.int64, device=device)   # write pointer, updated in place (the HIP rollout step shares it)
 
     def update(self, values, mask):
         """deque.extend(values[mask]) of common.Tracker: when more than max_len episodes finish in one step only the LAST
@@ -36,7 +36,7 @@ class DeviceTracker:
         keep = mask & (rank > total - self.max_len)
         pos = (self.ptr + rank - 1) % self.max_len
         self.ring.scatter_(0, torch.where(keep, pos, torch.full_like(pos, self.max_len)), values)
-        self.ptr = (self.ptr + total) % self.max_len
+        self.ptr.copy_((self.ptr + total) % self.max_len)
 
     def mean(self):
         return float(self.ring[: self.max_len].mean())
@@ -181,14 +181,15 @@ class PQLActor:
                 action = (self.get_actions(obs, sample=True) if draws is None
                           else self.get_actions(obs, sample=True, draw=draws[t].to(self.sim_device)))
             next_obs, reward, done, info = env.step(action)
-            self.update_tracker(reward, done, info)
-            if algo.handle_timeout:
-                done = handle_timeout(done, info)
-            sl["obs"][:, t] = obs
-            sl["act"][:, t] = action
-            sl["rew"][:, t, 0] = reward
-            sl["nobs"][:, t] = next_obs
-            sl["done"][:, t, 0] = done
+            if not self._bookkeep_hip(sl, t, timesteps, obs, action, next_obs, reward, done, info):
+                self.update_tracker(reward, done, info)
+                if algo.handle_timeout:
+                    done = handle_timeout(done, info)
+                sl["obs"][:, t] = obs
+                sl["act"][:, t] = action
+                sl["rew"][:, t, 0] = reward
+                sl["nobs"][:, t] = next_obs
+                sl["done"][:, t, 0] = done
             obs = next_obs
         self.obs = obs
         rew = sl["rew"] * algo.reward_scale
@@ -209,6 +210,29 @@ class PQLActor:
             p_data = H.shipper(self.sim_device, self.p_learner_device, "obs").ship((blk[0],), H.lease_of(blk))
             p_data = H.tag(p_data[0], H.lease_of(p_data))
         return p_data, v_data, timesteps * n
+
+    def _bookkeep_hip(self, sl, t, T, obs, action, next_obs, reward, done, info):
+        """Slab writes + episode accumulators + moving windows + handle_timeout of one env step as ONE launch
+        (`pqlk_rollout_step`); False = shapes / dtypes the kernel does not take (the torch ops below then do the same)."""
+        import ctypes as C
+        from pql_amd import _lib as L
+        if self.sim_device.type != "cuda" or done.dtype != torch.bool or reward.dtype != torch.float32:
+            return False
+        trunc = info.get("TimeLimit.truncated", None) if (self.cfg.algo.handle_timeout and isinstance(info, dict)) else None
+        if trunc is not None and trunc.dtype != torch.bool:
+            return False
+        tens = (obs, action, next_obs, reward)
+        if any(x.dtype != torch.float32 or not x.is_contiguous() for x in tens) or not done.is_contiguous():
+            return False
+        n, O = obs.shape[0], obs.shape[1]
+        with torch.cuda.device(self.sim_device):
+            L.check(L.lib.pqlk_rollout_step(n, O, self.action_dim, T, t, L.ptr(obs), L.ptr(action), L.ptr(next_obs), L.ptr(reward),
+                                            C.c_void_p(done.data_ptr()), C.c_void_p(trunc.data_ptr()) if trunc is not None else None,
+                                            L.ptr(sl["obs"]), L.ptr(sl["act"]), L.ptr(sl["rew"]), L.ptr(sl["nobs"]), L.ptr(sl["done"]),
+                                            L.ptr(self.current_returns), L.ptr(self.current_lengths), L.ptr(self.return_tracker.ring),
+                                            L.ptr(self.step_tracker.ring), L.ptr(self.return_tracker.ptr), L.ptr(self.step_tracker.ptr),
+                                            self.return_tracker.max_len, L.stream(self.sim_device)))
+        return True
 
     def update_tracker(self, reward, done, info):
         """Episode return / length windows, updated with masked scatters on the device (the reference's
