@@ -421,7 +421,11 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
     // further trips.  Measured at cfg 5 (32768 rows x 1 KiB, pads not re-zeroed; tools/bench_gather.py): 24 waves/CU x 2 rows
     // 18.5 us, 16 x 2 19.5, 12 x 2 21.4, 32 x 2 22.3, 16 x 4 20.3, 32 x 4 (one trip per wave, the round-1 shape) 23.0, 8 rows
     // in flight 30; at cfg 2 (8192 rows, one trip whatever the cap) 2 rows per wave 7.1 us vs 8.1 (4) and 9.0 (1).
-    // Non-temporal record loads: no gain (18.9 vs 18.5).
+    // Non-temporal record loads: no gain (18.9 vs 18.5).  Requesting trip k+1's records before trip k is normalised and stored
+    // (software pipeline): WORSE, 21.5 us -- on gfx9 stores share the in-order vmcnt queue with loads, so the wait for the
+    // prefetched records also waits for the previous trip's store acknowledgements.  With the ring small enough to sit in the
+    // Infinity Cache (51 MB) the same launch takes 14.9 us: the 5-GB ring's random 1-KiB reads cost ~4 us on top of that, and
+    // ring size hardly matters beyond the cache (0.25 GB 18.0 us, 5 GB 19.3, 20 GB 20.1: not a TLB effect).
     int R = 2;
     if (g_gather_R) R = g_gather_R;
     int64_t fb = (b + 4 * R - 1) / (4 * R);
