@@ -425,7 +425,11 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
     // (software pipeline): WORSE, 21.5 us -- on gfx9 stores share the in-order vmcnt queue with loads, so the wait for the
     // prefetched records also waits for the previous trip's store acknowledgements.  With the ring small enough to sit in the
     // Infinity Cache (51 MB) the same launch takes 14.9 us: the 5-GB ring's random 1-KiB reads cost ~4 us on top of that, and
-    // ring size hardly matters beyond the cache (0.25 GB 18.0 us, 5 GB 19.3, 20 GB 20.1: not a TLB effect).
+    // ring size hardly matters beyond the cache (0.25 GB 18.0 us, 5 GB 19.3, 20 GB 20.1: not a TLB effect).  A loader / consumer
+    // split (one wave per workgroup issuing LDS-DMA record loads into a 16-slot LDS ring behind a counted vmcnt, three waves
+    // normalising and storing out of the ring, so that no wave ever mixes loads and stores) was built and measured too:
+    // 20.2 us at best -- no better than this kernel, i.e. the limit is the memory system's rate for this mix (about 4 TB/s of
+    // bytes moved), not the way one wave's loads and stores queue.
     int R = 2;
     if (g_gather_R) R = g_gather_R;
     int64_t fb = (b + 4 * R - 1) / (4 * R);
