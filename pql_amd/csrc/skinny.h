@@ -303,15 +303,18 @@ __global__ __launch_bounds__(256) void k_skinny_bwd(SkinnyP p, float* __restrict
     for (int c = 0; c < CH; ++c) acc[n][c] = make_float4(0.f, 0.f, 0.f, 0.f);
   float dbacc = 0.f;   // lane n < N: sum of dY[:, n] over this wave's rows
   const int m_blk = blockIdx.x * rows_per_block;
-  // rows m_blk + wave + 4 j, j = 0 .. rows_per_block / 4 - 1, taken four at a time: all 4 x CH activation loads and the 4 dY
+  // rows m_blk + wave + 4 j, j = 0 .. rows_per_block / 4 - 1, taken RIF at a time: all RIF x CH activation loads and the RIF dY
   // loads of a group are requested before the first is used
-  for (int j0 = 0; j0 < rows_per_block / 4; j0 += 4) {
-    float4 xv[4][CH];
-    float dyl[4];
+  // rows in flight per wave (all their loads requested before the first is used): 8 for the wide heads, whose per-row
+  // arithmetic (N x 8 FMAs + N LDS reads) leaves few waves resident (actor head: P free-running +0.7 %); 4 for the scalar head
+  constexpr int RIF = (CH == 1 && NB >= 8) ? 8 : 4;
+  for (int j0 = 0; j0 < rows_per_block / 4; j0 += RIF) {
+    float4 xv[RIF][CH];
+    float dyl[RIF];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < RIF; ++u) {
       const int m = m_blk + wave + 4 * (j0 + u);
-      const bool ok = m < p.M;
+      const bool ok = m < p.M && j0 + u < rows_per_block / 4;
 #pragma unroll
       for (int c = 0; c < CH; ++c) {
         const int q = lane + 64 * c;
@@ -320,8 +323,9 @@ __global__ __launch_bounds__(256) void k_skinny_bwd(SkinnyP p, float* __restrict
       dyl[u] = (ok && lane < p.N) ? dY[(long long)m * p.ldy + lane] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < RIF; ++u) {
       const int m = m_blk + wave + 4 * (j0 + u);
+      if (j0 + u >= rows_per_block / 4) break;
       float dn[NB];
 #pragma unroll
       for (int n = 0; n < NB; ++n) dn[n] = __shfl(dyl[u], n, 64);
