@@ -713,3 +713,49 @@ def test_mlp_shape_sweep_vs_oracle(dev, ref, dims, nets, B, fused):
             scale = np.abs(gw).max() + 1e-12
             np.testing.assert_allclose(lay.weight(grads, n, l).cpu().numpy(), gw, rtol=1e-4, atol=2e-5 * scale, err_msg=f"dW net {n} layer {l}")
             np.testing.assert_allclose(lay.bias(grads, n, l).cpu().numpy(), gb, rtol=1e-4, atol=2e-5 * max(scale, np.abs(gb).max()), err_msg=f"db net {n} layer {l}")
+
+
+# --------------------------------------------------------------------------- one-launch rollout bookkeeping
+@pytest.mark.parametrize("N,O,A,win,H", [(1500, 13, 5, 7, 3), (4096, 88, 16, 100, 1), (64, 8, 2, 150, 2), (2049, 12, 4, 5, 2)])
+def test_rollout_step_kernel_vs_reference_semantics(dev, N, O, A, win, H):
+    """pqlk_rollout_step against a plain restatement of pql_actor.py:104-114,129-135 + common.py:195-202: slab columns,
+    done' = done * !truncated, return / length accumulators, and the two moving windows as `deque.extend` of the finished envs'
+    values in env order -- including steps where nobody, everybody, or more envs than the window holds finish, env counts
+    that are not a multiple of the 1024-wide scan chunk, and field widths that are not multiples of 4."""
+    from collections import deque
+    from pql_amd import _lib as L
+    rng = np.random.default_rng(N + O)
+    f = dict(dtype=torch.float32, device=dev)
+    sl = [torch.full((N, H, w), -7.0, **f) for w in (O, A, 1, O, 1)]
+    cur_ret, cur_len = torch.zeros(N, **f), torch.zeros(N, **f)
+    win_ret, win_len = torch.zeros(win + 1, **f), torch.zeros(win + 1, **f)
+    ptr_r, ptr_l = torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
+    ref_ret, ref_len = np.zeros(N, np.float32), np.zeros(N, np.float32)
+    dq_r, dq_l = deque([0.0] * win, maxlen=win), deque([0.0] * win, maxlen=win)
+    want = [np.full((N, H, w), -7.0, np.float32) for w in (O, A, 1, O, 1)]
+    for rep in range(4):
+        for t in range(H):
+            p_done = (0.0, 0.02, 1.0, 0.4)[(rep + t) % 4]
+            obs, act, nobs = (rng.normal(size=(N, w)).astype(np.float32) for w in (O, A, O))
+            rew = rng.normal(size=N).astype(np.float32)
+            done = rng.random(N) < p_done
+            trunc = (rng.random(N) < 0.3) if rep % 2 else None
+            d_obs, d_act, d_nobs, d_rew = (T(x).to(dev) for x in (obs, act, nobs, rew))
+            d_done = T(done).to(dev)
+            d_trunc = T(trunc).to(dev) if trunc is not None else None
+            L.check(L.lib.pqlk_rollout_step(N, O, A, H, t, L.ptr(d_obs), L.ptr(d_act), L.ptr(d_nobs), L.ptr(d_rew),
+                                            C.c_void_p(d_done.data_ptr()), C.c_void_p(d_trunc.data_ptr()) if d_trunc is not None else None,
+                                            *[L.ptr(x) for x in sl], L.ptr(cur_ret), L.ptr(cur_len), L.ptr(win_ret), L.ptr(win_len),
+                                            L.ptr(ptr_r), L.ptr(ptr_l), win, L.stream(dev)))
+            torch.cuda.synchronize()
+            want[0][:, t], want[1][:, t], want[2][:, t, 0], want[3][:, t] = obs, act, rew, nobs
+            want[4][:, t, 0] = (done & ~trunc if trunc is not None else done).astype(np.float32)
+            ref_ret += rew; ref_len += 1
+            dq_r.extend(ref_ret[done].tolist()); dq_l.extend(ref_len[done].tolist())
+            ref_ret[done] = 0; ref_len[done] = 0
+            assert np.array_equal(cur_ret.cpu().numpy(), ref_ret) and np.array_equal(cur_len.cpu().numpy(), ref_len)
+            assert sorted(win_ret[:win].cpu().tolist()) == sorted(np.float32(x) for x in dq_r)
+            assert sorted(win_len[:win].cpu().tolist()) == sorted(np.float32(x) for x in dq_l)
+            assert int(ptr_r.item()) == int(ptr_l.item()) < win
+        for got, exp in zip(sl, want):
+            assert np.array_equal(got.cpu().numpy(), exp)
