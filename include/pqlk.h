@@ -216,6 +216,16 @@ int32_t pqlk_mlp_norm_parts(const PqlMlpDesc* d);
  * "skip the pad stores" and non-temporal record loads for the next launches (0 = automatic / off). */
 int pqlk_tune_gather(int rows_in_flight, int waves_per_cu, int nopad, int nt_loads);
 
+/* DPG backward through the frozen twin critic (pql_p_learner.py:55-58): the input gradient of pqlk_mlp_backward's
+ * (grads = NULL, dx + dx_tanh_of) form.  With scalar Q heads the gradient of min(Q1, Q2) reaches one net per sample, so the
+ * samples are first partitioned by owning net and the dX chain runs over compact rows -- half the MFMA work, each sample's
+ * values bit for bit those of the dense chain; other critics take the dense chain.  dx (B, ld_dx) is fully overwritten
+ * (columns >= dx_cols with zero).  ws >= pqlk_dpg_backward_ws_floats(d, b) floats. */
+int64_t pqlk_dpg_backward_ws_floats(const PqlMlpDesc* d, int64_t b);
+int pqlk_dpg_critic_backward(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                             const float* acts, const float* dy, float* dx, int64_t ld_dx, int32_t dx_col0, int32_t dx_cols,
+                             const float* dx_tanh_of, int64_t ld_tanh, float* ws, int64_t ws_floats, pqlk_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Losses.  Each writes dy (2, B, ld) for pqlk_mlp_backward and one scalar loss (device), via per-block
  * partials in `scratch` (>= 1024 floats) reduced in fixed order.  The scalar lands in

@@ -129,7 +129,7 @@ class PQLPLearner:
         ws["dz_a"] = torch.zeros((1, B, ws["ld_a"]), **f)   # dL/d(actor pre-tanh); pad columns stay zero
         ws["grads"] = torch.zeros(al.total, **f)
         ws["splits"] = default_splits(B)
-        ws["bwd_c"] = torch.empty(cl.bwd_ws_floats(B, 1), **f)
+        ws["bwd_c"] = torch.empty(int(L.lib.pqlk_dpg_backward_ws_floats(C.byref(cl.desc), B)), **f)
         ws["bwd_a"] = torch.empty(al.bwd_ws_floats(B, ws["splits"]), **f)
         ws["scratch"] = torch.zeros(2048, **f)
         self._ws = ws
@@ -165,9 +165,11 @@ class PQLPLearner:
         L.check(L.lib.pqlk_dpg_loss(L.ptr(q), cl.ld_out, K, L.ptr(z), B, L.ptr(ws["dy_c"]), None if tail else L.ptr(self.loss_ring),
                                     L.ptr(self.opt.step), LOSS_RING, L.ptr(ws["scratch"]), st))
         a_out = output_view(al, ws["acts_a"], B)  # (1, B, ld_a): tanh output, for the tanh' chain
-        L.check(L.lib.pqlk_mlp_backward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
-                                        L.ptr(ws["acts_c"]), L.ptr(ws["dy_c"]), None, 1, L.ptr(ws["dz_a"]), ws["ld_a"], O, A,
-                                        L.ptr(a_out), ws["ld_a"], L.ptr(ws["bwd_c"]), ws["bwd_c"].numel(), st))
+        # dX-only chain through the frozen critic; with scalar Q heads it runs over the samples partitioned by the net that
+        # attained min(Q1, Q2): the other net's rows of every dZ are exactly zero (csrc/minnet.h)
+        L.check(L.lib.pqlk_dpg_critic_backward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
+                                               L.ptr(ws["acts_c"]), L.ptr(ws["dy_c"]), L.ptr(ws["dz_a"]), ws["ld_a"], O, A,
+                                               L.ptr(a_out), ws["ld_a"], L.ptr(ws["bwd_c"]), ws["bwd_c"].numel(), st))
         if tail:
             L.check(L.lib.pqlk_mlp_backward_norm(C.byref(al.desc), L.ptr(self.actor.arena.data), L.ptr(ws["x_obs"]), ws["ld_o"], B,
                                                  L.ptr(ws["acts_a"]), L.ptr(ws["dz_a"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0,

@@ -48,9 +48,16 @@ struct GemmP {
   int col0, ncol;     // DX/DTANH_SLICE: only columns [col0, col0+ncol) are written, compacted to column 0
   int n_base;         // first output column covered by the grid (multiple of 4)
   float noise_std, noise_clip;
+  // "min-net" compaction of the DPG backward (minnet.h): rows of A / C are COMPACT rows -- the samples whose min(Q1, Q2) came
+  // from net 0, then (from row mn[2] on, a multiple of 128) those of net 1 -- perm[i] = batch row of compact row i (-1: pad),
+  // mn = {c0, c1, first row of net 1, rows in use (multiple of 128)}.  A row tile belongs to ONE net: the block picks that
+  // net's weights (B) and activations (aux, row perm[i]); tiles past mn[3] exit at once.
+  const int* perm;
+  const int* mn;
 };
 
 #include "narrow.h"
+#include "minnet.h"
 
 #define KT_MAX 32   // reduction elements per LDS stage (template parameter KT: 32 or 16)
 #ifndef PQLK_KT
@@ -164,7 +171,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int m0 = blockIdx.y * BM, n0 = p.n_base + blockIdx.x * BN;
 
   int g0 = 0, g1 = 1, split = 0;
-  if (MODE == MODE_DW) {
+  if (MODE == MODE_DX && p.perm) {   // compact rows: one net per row tile (sA = sC = 0, grid.z = 1 on the host side)
+    if (m0 >= p.mn[3]) return;       // block-uniform, before any barrier
+    g0 = m0 >= p.mn[2] ? 1 : 0;
+    g1 = g0 + 1;
+  } else if (MODE == MODE_DW) {
     g0 = blockIdx.z / p.splits;
     split = blockIdx.z % p.splits;
     g1 = g0 + 1;
@@ -402,7 +413,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const long long grow = m0 + wm + 32 * i + rr;
           const int gcol = n0 + wn + 4 * pc4;
           if (EPI == EPI_DELU) {
-            const float4 h4 = *reinterpret_cast<const float4*>(auxw + grow * p.ldaux + gcol);
+            long long arow = grow;
+            if (MODE == MODE_DX && p.perm) { const int pr = p.perm[grow]; arow = pr < 0 ? 0 : pr; }   // pad rows: dZ is zero anyway
+            const float4 h4 = *reinterpret_cast<const float4*>(auxw + arow * p.ldaux + gcol);
             v.x = h4.x > 0.f ? v.x : v.x * (h4.x + 1.f);  // ELU'(x) = exp(x) = elu(x) + 1 for x <= 0
             v.y = h4.y > 0.f ? v.y : v.y * (h4.y + 1.f);
             v.z = h4.z > 0.f ? v.z : v.z * (h4.z + 1.f);
@@ -1074,6 +1087,109 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
     const int extra = head_blocks > 0 ? (int)((head_quads(d) + 3) / 4) : 0;
     hipLaunchKernelGGL(k_reduce_slabs, dim3(r.main_blocks + extra), dim3(256), 0, st, r);
     PQLK_LAUNCH_CHECK();
+  }
+  return PQLK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// DPG backward through the frozen twin critic (pql_p_learner.py:55-58): input gradient only, action columns only, chained
+// through the actor's tanh.  With scalar Q heads the samples are partitioned by the net that attained min(Q1, Q2) and the dX
+// chain runs over compact rows (minnet.h): half the MFMA work of the dense chain, same per-sample bits.  Anything else
+// (distributional heads, widths that are not multiples of 128, a single net) takes the dense chain of pqlk_mlp_backward.
+static bool minnet_ok(const PqlMlpDesc* d, const float* dx, const float* dx_tanh_of, int dx_cols) {
+  const int L = d->n_layers;
+  if (d->n_nets != 2 || L < 3 || d->dims[L] != 1 || !dx || !dx_tanh_of || dx_cols > 32) return false;
+  if (!skinny_bwd_ok(1, (int)pqlk_ld(d->dims[L - 1]))) return false;
+  for (int l = 1; l < L; ++l)
+    if (d->dims[l] % 32 != 0) return false;
+  for (int l = 1; l < L - 1; ++l)
+    if (d->dims[l] % 128 != 0) return false;   // output width of the dX GEMM of layer l + 1: whole 128-column tiles
+  return true;
+}
+static int64_t minnet_rows_cap(int64_t b) { return 2 * pqlk_round_up(b, MN_TILE); }   // every sample a tie: both runs full
+
+extern "C" int64_t pqlk_dpg_backward_ws_floats(const PqlMlpDesc* d, int64_t b) {
+  if (desc_ok(d) || b <= 0) return 0;
+  const int64_t dense = pqlk_mlp_bwd_ws_floats(d, b, 1);
+  const int64_t compact = 2 * minnet_rows_cap(b) * max_hidden_ld(d) + minnet_rows_cap(b) + 64;   // two dZ buffers, perm, mn
+  return dense > compact ? dense : compact;
+}
+
+extern "C" int pqlk_dpg_critic_backward(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                                        const float* acts, const float* dy, float* dx, int64_t ld_dx, int32_t dx_col0,
+                                        int32_t dx_cols, const float* dx_tanh_of, int64_t ld_tanh, float* ws, int64_t ws_floats,
+                                        pqlk_stream_t stream) {
+  int rc = desc_ok(d);
+  if (rc) return rc;
+  PQLK_REQUIRE(ws_floats >= pqlk_dpg_backward_ws_floats(d, b), PQLK_E_WORKSPACE);
+  if (!minnet_ok(d, dx, dx_tanh_of, dx_cols))
+    return mlp_backward_impl(d, params, x, ldx, b, acts, dy, nullptr, 1, dx, ld_dx, dx_col0, dx_cols, dx_tanh_of, ld_tanh, ws, ws_floats,
+                             nullptr, nullptr, stream);
+  PQLK_REQUIRE(params && acts && dy && ws, PQLK_E_NULL);
+  PQLK_REQUIRE(b > 0 && b < (1LL << 29), PQLK_E_SHAPE);
+  PQLK_REQUIRE(ld_dx % 32 == 0 && dx_col0 >= 0 && dx_cols > 0 && dx_col0 + dx_cols <= d->dims[0] && ld_dx >= dx_cols, PQLK_E_RANGE);
+  const int L = d->n_layers;
+  const int64_t net_stride = pqlk_mlp_net_stride(d);
+  const int64_t rows_cap = minnet_rows_cap(b), mld = max_hidden_ld(d);
+  float* dz[2] = {ws, ws + rows_cap * mld};
+  int* perm = reinterpret_cast<int*>(ws + 2 * rows_cap * mld);
+  int* mn = perm + rows_cap;
+  hipStream_t st = pqlk_s(stream);
+  // 1. partition by owning net (+ zero the action-gradient matrix the slice kernel adds into)
+  int64_t q_off, q_ld;
+  pqlk_mlp_act_offset(d, b, 0, L - 1, &q_off, &q_ld);
+  hipLaunchKernelGGL(k_minnet_partition, dim3(1), dim3(1024), 0, st, acts + q_off, q_ld, b, perm, rows_cap, mn, dx, b * ld_dx);
+  PQLK_LAUNCH_CHECK();
+  // 2. head: dZ_{L-1} in compact rows
+  {
+    int64_t w_off, b_off, h_off, h_ld;
+    pqlk_mlp_layer_offsets(d, L - 1, &w_off, &b_off);
+    pqlk_mlp_act_offset(d, b, 0, L - 2, &h_off, &h_ld);
+    MinnetHeadP h = {};
+    h.H = acts + h_off; h.sH = b * h_ld; h.ldh = (int)h_ld;
+    h.W = params + w_off; h.sW = net_stride; h.ldk = (int)pqlk_ld(d->dims[L - 1]);
+    h.dY = dy; h.sY = b * pqlk_ld(1); h.ldy = (int)pqlk_ld(1);
+    h.C = dz[0]; h.perm = perm; h.mn = mn; h.N = 1; h.K = h.ldk; h.rows_cap = rows_cap;
+    int64_t blocks = rows_cap / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_minnet_head_dx, dim3((unsigned)blocks), dim3(256), (size_t)2 * h.N * h.K * sizeof(float), st, h);
+    PQLK_LAUNCH_CHECK();
+  }
+  // 3. hidden layers: dH_{l-1} = (dZ_l W_l) * ELU'(H_{l-1}) over compact rows, one net per 128-row tile
+  int flip = 0;
+  for (int l = L - 2; l >= 1; --l) {
+    int64_t w_off, b_off, a_off, a_ld;
+    pqlk_mlp_layer_offsets(d, l, &w_off, &b_off);
+    pqlk_mlp_act_offset(d, b, 0, l - 1, &a_off, &a_ld);
+    GemmP p = {};
+    p.A = dz[flip]; p.lda = (int)pqlk_ld(d->dims[l + 1]); p.sA = 0;
+    p.B = params + w_off; p.ldb = (int)pqlk_ld(d->dims[l]); p.sB = net_stride;
+    p.C = dz[flip ^ 1]; p.ldc = (int)pqlk_ld(d->dims[l]); p.sC = 0;
+    p.aux = acts + a_off; p.ldaux = (int)a_ld; p.sAux = b * a_ld;
+    p.M = (int)rows_cap; p.N = d->dims[l]; p.K = d->dims[l + 1];
+    p.ncols_store = p.ldc;
+    p.groups = 2; p.zsum = 0; p.epi = EPI_DELU;
+    p.perm = perm; p.mn = mn;
+    rc = launch_gemm<MODE_DX, 128, 128, EPI_DELU>(p, 1, st);
+    if (rc) return rc;
+    flip ^= 1;
+  }
+  // 4. first layer: action columns only, through tanh', scattered back to batch rows
+  {
+    int64_t w_off, b_off;
+    pqlk_mlp_layer_offsets(d, 0, &w_off, &b_off);
+    GemmP p = {};
+    p.A = dz[flip]; p.lda = (int)pqlk_ld(d->dims[1]); p.sA = 0;
+    p.B = params + w_off; p.ldb = (int)pqlk_ld(d->dims[0]); p.sB = net_stride;
+    p.C = dx; p.ldc = (int)ld_dx; p.sC = 0;
+    p.M = (int)rows_cap; p.N = d->dims[0]; p.K = d->dims[1];
+    p.ncols_store = p.ldb;
+    p.groups = 1; p.zsum = 1;
+    p.epi = EPI_DTANH_SLICE; p.aux = dx_tanh_of; p.ldaux = (int)ld_tanh; p.col0 = dx_col0; p.ncol = dx_cols;
+    p.perm = perm; p.mn = mn;
+    PQLK_REQUIRE(dx_slice_ok(p), PQLK_E_UNSUPPORTED);
+    rc = launch_dx_slice(p, st);
+    if (rc) return rc;
   }
   return PQLK_OK;
 }

@@ -1,0 +1,123 @@
+// "Min-net" compaction of the DPG backward through the frozen twin critic.
+//
+// Reference: pql/algo/pql_p_learner.py:55-58 -- actor_loss = -critic.get_q_min(obs, actor(obs)).mean(), i.e.
+// min(Q1, Q2) per sample (pql/models/mlp.py:201-203).  Its gradient reaches only the net that attained the minimum
+// (both, halved, on an exact tie), so in the dense backward half of the (net, sample) rows of every dZ are exactly zero and
+// the dX GEMMs multiply them through three layers.  Here the samples are PARTITIONED by the net that owns them first:
+//   compact rows [0, c0)            samples with Q1 <= Q2 (ties included), in batch order          -> net 0's weights
+//   compact rows [base1, base1+c1)  samples with Q2 <= Q1 (ties included), base1 = c0 rounded up to 128 -> net 1's weights
+// so every 128-row GEMM tile belongs to ONE net and the chain runs over ~B (+ ties + padding) rows instead of 2 B: half
+// the MFMA work of the critic backward.  Rows are computed independently of each other, so each sample's dZ is bit for bit
+// what the dense chain computes for it; the final scatter adds one or (tie) two contributions per action gradient.
+// Used when the critic has scalar Q heads (the distributional head's minimum is over expectations: dense path).
+#pragma once
+#include "pqlk_common.h"
+
+#define MN_TILE 128
+
+// One block: stable partition of the batch by the owning net + zero-fill of the action-gradient matrix the slice
+// kernel accumulates into.  q = (2, B, ldq) head outputs (column 0).  mn = {c0, c1, base1, rows in use}.
+__global__ __launch_bounds__(1024) void k_minnet_partition(const float* __restrict__ q, int64_t ldq, int64_t b, int* __restrict__ perm,
+                                                           int64_t perm_len, int* __restrict__ mn, float* __restrict__ zero_out,
+                                                           int64_t zero_floats) {
+  __shared__ int w0[16], w1[16];
+  __shared__ int s_c0, s_c1, s_b0, s_b1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t i = threadIdx.x; i < (zero_floats >> 2); i += 1024) reinterpret_cast<float4*>(zero_out)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  // pass 1: counts
+  int n0 = 0, n1 = 0;
+  for (int64_t m = threadIdx.x; m < b; m += 1024) {
+    const float a = q[m * ldq], c = q[(b + m) * ldq];
+    n0 += a <= c; n1 += c <= a;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { n0 += __shfl_xor(n0, o, 64); n1 += __shfl_xor(n1, o, 64); }
+  if (lane == 0) { w0[wave] = n0; w1[wave] = n1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int a = 0, c = 0;
+    for (int w = 0; w < 16; ++w) { a += w0[w]; c += w1[w]; }
+    s_c0 = a; s_c1 = c; s_b0 = 0; s_b1 = 0;
+  }
+  __syncthreads();
+  const int c0 = s_c0, c1 = s_c1;
+  const int base1 = (c0 + MN_TILE - 1) / MN_TILE * MN_TILE;
+  const int used = base1 + (c1 + MN_TILE - 1) / MN_TILE * MN_TILE;
+  // pad rows of the two runs
+  for (int64_t i = c0 + threadIdx.x; i < base1; i += 1024) perm[i] = -1;
+  for (int64_t i = base1 + c1 + threadIdx.x; i < used && i < perm_len; i += 1024) perm[i] = -1;
+  // pass 2: ordered positions (chunks of 1024 samples, running bases)
+  for (int64_t m0 = 0; m0 < b; m0 += 1024) {
+    const int64_t m = m0 + threadIdx.x;
+    bool f0 = false, f1 = false;
+    if (m < b) { const float a = q[m * ldq], c = q[(b + m) * ldq]; f0 = a <= c; f1 = c <= a; }
+    const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (lane == 0) { w0[wave] = __popcll(b0); w1[wave] = __popcll(b1); }
+    __syncthreads();
+    int p0 = s_b0 + __popcll(b0 & below), p1 = s_b1 + __popcll(b1 & below);
+    for (int w = 0; w < wave; ++w) { p0 += w0[w]; p1 += w1[w]; }
+    if (f0) perm[p0] = (int)m;
+    if (f1) perm[base1 + p1] = (int)m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int a = 0, c = 0;
+      for (int w = 0; w < 16; ++w) { a += w0[w]; c += w1[w]; }
+      s_b0 += a; s_b1 += c;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { mn[0] = c0; mn[1] = c1; mn[2] = base1; mn[3] = used; }
+}
+
+// Head backward (dX only, <= 16 outputs) straight into compact rows:
+//   dZ[i, :] = (sum_n dY[net, m, n] W_net[n, :]) * ELU'(H[net, m, :]),  m = perm[i], net = run of row i;  pad rows -> 0.
+// One wave per compact row, both nets' head weights in LDS.
+struct MinnetHeadP {
+  const float* H; long long sH; int ldh;        // (2, B, ldh) last hidden activations
+  const float* W; long long sW; int ldk;        // (N, ldk) per net
+  const float* dY; long long sY; int ldy;       // (2, B, ldy)
+  float* C;                                     // (rows, ldk) compact output
+  const int* perm; const int* mn;
+  int N, K; long long rows_cap;
+};
+
+__global__ __launch_bounds__(256) void k_minnet_head_dx(MinnetHeadP p) {
+  extern __shared__ __attribute__((aligned(16))) float mn_w[];   // (2, N, K)
+  const int kq = p.K >> 2;
+  for (int i = threadIdx.x; i < 2 * p.N * kq; i += 256) {
+    const int g = i / (p.N * kq), rem = i - g * p.N * kq, n = rem / kq, q = rem % kq;
+    reinterpret_cast<float4*>(mn_w)[i] = *reinterpret_cast<const float4*>(p.W + (long long)g * p.sW + (long long)n * p.ldk + 4 * q);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int used = p.mn[3], base1 = p.mn[2];
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < used; i += nwaves) {
+    const int m = p.perm[i];
+    const int g = i >= base1 ? 1 : 0;
+    float dyl = 0.f;
+    if (m >= 0 && lane < p.N) dyl = p.dY[(long long)g * p.sY + (long long)m * p.ldy + lane];
+    float dn[16];
+#pragma unroll
+    for (int n = 0; n < 16; ++n) dn[n] = __shfl(dyl, n, 64);
+    for (int q = lane; q < kq; q += 64) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m >= 0) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+          if (n < p.N) {
+            const float4 w = reinterpret_cast<const float4*>(mn_w)[(g * p.N + n) * kq + q];
+            a.x += dn[n] * w.x; a.y += dn[n] * w.y; a.z += dn[n] * w.z; a.w += dn[n] * w.w;
+          }
+        }
+        const float4 hv = *reinterpret_cast<const float4*>(p.H + (long long)g * p.sH + (long long)m * p.ldh + 4 * q);
+        a.x = hv.x > 0.f ? a.x : a.x * (hv.x + 1.f);
+        a.y = hv.y > 0.f ? a.y : a.y * (hv.y + 1.f);
+        a.z = hv.z > 0.f ? a.z : a.z * (hv.z + 1.f);
+        a.w = hv.w > 0.f ? a.w : a.w * (hv.w + 1.f);
+      }
+      *reinterpret_cast<float4*>(p.C + i * p.ldk + 4 * q) = a;
+    }
+  }
+}

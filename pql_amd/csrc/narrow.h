@@ -191,6 +191,15 @@ __global__ __launch_bounds__(256) void k_dx_slice(GemmP p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * 32;
+  // compact rows (GemmP::perm): this 32-row tile belongs to ONE net -- reduction over that net's K only (host: groups = 1);
+  // outputs go to batch row perm[i] by atomic add (a tie of the two Q heads puts a sample in both nets' runs: two addends,
+  // and a + b = b + a, so the result does not depend on which arrives first); tiles past the rows in use exit at once
+  int cnet = 0;
+  if (p.perm) {
+    if (m0 >= p.mn[3]) return;
+    cnet = m0 >= p.mn[2] ? 1 : 0;
+  }
+  const float* Bw = p.B + (long long)cnet * p.sB;      // (groups = 1 in compact mode, so the g * sB terms below vanish)
   const int ktot = p.groups * p.K;          // p.K = hidden width (multiple of 32)
   const int kq = ktot >> 2;                 // reduction elements of this wave; multiple of 8
   const int kbeg = wave * kq;
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(256) void k_dx_slice(GemmP p) {
           const int kg = kbeg + min(kk, kq - 1), g = kg / p.K, k = kg - g * p.K;
           v[b] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (i < kq * 8 && 4 * c4 < p.ncol)
-            v[b] = *reinterpret_cast<const float4*>(p.B + (long long)g * p.sB + (long long)k * p.ldb + p.col0 + 4 * c4);
+            v[b] = *reinterpret_cast<const float4*>(Bw + (long long)g * p.sB + (long long)k * p.ldb + p.col0 + 4 * c4);
         }
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -227,7 +236,7 @@ __global__ __launch_bounds__(256) void k_dx_slice(GemmP p) {
       for (int i = lane; i < kq * 32; i += 64) {
         const int kk = i >> 5, c = i & 31;
         const int kg = kbeg + kk, g = kg / p.K, k = kg - g * p.K;
-        wt[c * ldw + kk] = c < p.ncol ? p.B[(long long)g * p.sB + (long long)k * p.ldb + p.col0 + c] : 0.f;
+        wt[c * ldw + kk] = c < p.ncol ? Bw[(long long)g * p.sB + (long long)k * p.ldb + p.col0 + c] : 0.f;
       }
     }
   }
@@ -265,15 +274,20 @@ __global__ __launch_bounds__(256) void k_dx_slice(GemmP p) {
   for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = (acc4[0][e] + acc4[1][e]) + (acc4[2][e] + acc4[3][e]);
   __syncthreads();
   if (wave != 0) return;
-  const int orow = m0 + r;
+  int orow = m0 + r;
   if (orow >= p.M) return;
+  if (p.perm) {
+    orow = p.perm[orow];
+    if (orow < 0) return;   // pad row of the compact layout
+  }
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const float s = ((red[e * 64 + lane] + red[(16 + e) * 64 + lane]) + red[(32 + e) * 64 + lane]) + red[(48 + e) * 64 + lane];
     const int c = 8 * (e >> 2) + 4 * h + (e & 3);
     if (c < p.ncol) {
       const float a = p.aux[(long long)orow * p.ldaux + c];
-      p.C[(long long)orow * p.ldc + c] = s * (1.f - a * a);
+      if (p.perm) atomicAdd(&p.C[(long long)orow * p.ldc + c], s * (1.f - a * a));
+      else p.C[(long long)orow * p.ldc + c] = s * (1.f - a * a);
     }
   }
 }

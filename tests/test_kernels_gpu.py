@@ -759,3 +759,55 @@ def test_rollout_step_kernel_vs_reference_semantics(dev, N, O, A, win, H):
             assert int(ptr_r.item()) == int(ptr_l.item()) < win
         for got, exp in zip(sl, want):
             assert np.array_equal(got.cpu().numpy(), exp)
+
+
+# --------------------------------------------------------------------------- DPG backward: min-net compaction vs the dense chain
+@pytest.mark.parametrize("hidden,B", [((512, 512, 256), 1000), ((512, 256, 128), 4096), ((128, 128), 130), ((512, 512, 256), 8192)])
+def test_dpg_critic_backward_minnet_matches_dense_chain(dev, hidden, B):
+    """pqlk_dpg_critic_backward partitions the batch by the net that attained min(Q1, Q2) and runs the dX chain over compact
+    rows; pqlk_mlp_backward runs it densely over both nets with half the rows zero.  Same per-sample arithmetic, so the
+    action gradients must agree to reassociation error of the final 512-term reduction -- including exact ties (both nets
+    get half the gradient), a batch that is not a multiple of the 128-row tile, and every sample on one side."""
+    from pql_amd import _lib as L
+    from pql_amd.models.mlp import ArenaLayout, PackedWeights, mlp_forward_raw, output_view
+    O, A = 88, 16
+    lay = ArenaLayout([O + A, *hidden, 1], 2)
+    g = torch.Generator(device=dev).manual_seed(B)
+    arena = torch.zeros(lay.total, device=dev)
+    for n in range(2):
+        for l in range(lay.n_layers):
+            bound = 1.0 / np.sqrt(lay.dims[l])
+            lay.weight(arena, n, l).copy_((torch.rand(lay.weight(arena, n, l).shape, device=dev, generator=g) * 2 - 1) * bound)
+            lay.bias(arena, n, l).copy_((torch.rand(lay.dims[l + 1], device=dev, generator=g) * 2 - 1) * bound)
+    x = torch.zeros((B, lay.ld_in), device=dev)
+    x[:, : O + A] = torch.randn((B, O + A), device=dev, generator=g)
+    a_out = torch.zeros((1, B, L.ld(A)), device=dev)
+    a_out[0, :, :A] = torch.tanh(torch.randn((B, A), device=dev, generator=g))
+    pk = PackedWeights(lay, dev).refresh(arena)
+    for case in ("natural", "ties", "all_net1"):
+        acts = mlp_forward_raw(lay, arena, x, L.ACT_NONE, packed=pk, stash_all=True)
+        q = output_view(lay, acts, B)
+        if case == "ties":
+            q[1, ::7, 0] = q[0, ::7, 0]          # exact ties on every 7th sample
+        elif case == "all_net1":
+            q[1, :, 0] = q[0, :, 0] - 1.0        # net 1 owns every sample: run 0 is empty
+        dy = torch.zeros((2, B, lay.ld_out), device=dev)
+        ring = torch.zeros(5, device=dev); slot = torch.zeros(1, dtype=torch.int32, device=dev); scratch = torch.zeros(2048, device=dev)
+        L.check(L.lib.pqlk_dpg_loss(L.ptr(q), lay.ld_out, 1, None, B, L.ptr(dy), L.ptr(ring), L.ptr(slot), 5, L.ptr(scratch), L.stream(dev)))
+        outs = []
+        for compact in (False, True):
+            dz = torch.full((1, B, L.ld(A)), 3.0 if compact else 0.0, device=dev)   # the compact path must zero it itself
+            if compact:
+                ws = torch.empty(int(L.lib.pqlk_dpg_backward_ws_floats(C.byref(lay.desc), B)), device=dev)
+                L.check(L.lib.pqlk_dpg_critic_backward(C.byref(lay.desc), L.ptr(arena), L.ptr(x), lay.ld_in, B, L.ptr(acts), L.ptr(dy),
+                                                       L.ptr(dz), L.ld(A), O, A, L.ptr(a_out), L.ld(A), L.ptr(ws), ws.numel(), L.stream(dev)))
+            else:
+                ws = torch.empty(lay.bwd_ws_floats(B, 1), device=dev)
+                L.check(L.lib.pqlk_mlp_backward(C.byref(lay.desc), L.ptr(arena), L.ptr(x), lay.ld_in, B, L.ptr(acts), L.ptr(dy), None, 1,
+                                                L.ptr(dz), L.ld(A), O, A, L.ptr(a_out), L.ld(A), L.ptr(ws), ws.numel(), L.stream(dev)))
+            torch.cuda.synchronize()
+            outs.append(dz.clone())
+        dense, comp = outs
+        assert float(dense.abs().max()) > 0
+        torch.testing.assert_close(comp[0, :, :A], dense[0, :, :A], rtol=2e-5, atol=1e-9 + 2e-6 * float(dense.abs().max()))
+        assert torch.all(comp[0, :, A:] == 0)
