@@ -224,7 +224,8 @@ int pqlk_tune_gather(int rows_in_flight, int waves_per_cu, int nopad, int nt_loa
 int64_t pqlk_dpg_backward_ws_floats(const PqlMlpDesc* d, int64_t b);
 int pqlk_dpg_critic_backward(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
                              const float* acts, const float* dy, float* dx, int64_t ld_dx, int32_t dx_col0, int32_t dx_cols,
-                             const float* dx_tanh_of, int64_t ld_tanh, float* ws, int64_t ws_floats, pqlk_stream_t stream);
+                             const float* dx_tanh_of, int64_t ld_tanh, const uint8_t* owner /* (B) from pqlk_dpg_loss_owner, or NULL */,
+                             float* ws, int64_t ws_floats, pqlk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Losses.  Each writes dy (2, B, ld) for pqlk_mlp_backward and one scalar loss (device), via per-block
@@ -258,6 +259,10 @@ int pqlk_c51_project(const float* p, const float* rew, const float* done, const 
 /* DPG actor loss (pql_p_learner.py:56-57): L = -mean(min(Q1,Q2)); dy = dL/dQ (ties split evenly, as
  * torch.min's backward).  k == 1: q (2,B,ld) scalar heads.  k > 1: logits of the distributional critic,
  * Q_i = sum softmax(logits_i) * z (mlp.py:256-260), dy = gradient w.r.t. the logits. */
+int pqlk_dpg_loss_owner(const float* q, int64_t ld, int32_t k, const float* support, int64_t b, float* dy, float* loss_out,
+                        const int32_t* slot_dev, int32_t ring_len, float* scratch,
+                        uint8_t* owner /* (B), k == 1: bit 0 / bit 1 = the gradient of min(Q1, Q2) reaches net 0 / net 1 */,
+                        pqlk_stream_t stream);
 int pqlk_dpg_loss(const float* q, int64_t ld, int32_t k, const float* support /*(K), NULL when k == 1*/, int64_t b,
                   float* dy, float* loss_out, const int32_t* slot_dev, int32_t ring_len, float* scratch,
                   pqlk_stream_t stream);

@@ -130,6 +130,7 @@ class PQLPLearner:
         ws["grads"] = torch.zeros(al.total, **f)
         ws["splits"] = default_splits(B)
         ws["bwd_c"] = torch.empty(int(L.lib.pqlk_dpg_backward_ws_floats(C.byref(cl.desc), B)), **f)
+        ws["owner"] = torch.zeros(B, dtype=torch.uint8, device=self.device)   # which net(s) own each sample's min(Q1, Q2)
         ws["bwd_a"] = torch.empty(al.bwd_ws_floats(B, ws["splits"]), **f)
         ws["scratch"] = torch.zeros(2048, **f)
         self._ws = ws
@@ -162,14 +163,15 @@ class PQLPLearner:
         K = int(getattr(self.critic, "num_atoms", 1))
         z = getattr(self.critic, "z_atoms", None) if K > 1 else None
         tail = self._fused_tail   # see PQLVLearner._step_kernels
-        L.check(L.lib.pqlk_dpg_loss(L.ptr(q), cl.ld_out, K, L.ptr(z), B, L.ptr(ws["dy_c"]), None if tail else L.ptr(self.loss_ring),
-                                    L.ptr(self.opt.step), LOSS_RING, L.ptr(ws["scratch"]), st))
+        L.check(L.lib.pqlk_dpg_loss_owner(L.ptr(q), cl.ld_out, K, L.ptr(z), B, L.ptr(ws["dy_c"]), None if tail else L.ptr(self.loss_ring),
+                                          L.ptr(self.opt.step), LOSS_RING, L.ptr(ws["scratch"]), C.c_void_p(ws["owner"].data_ptr()), st))
         a_out = output_view(al, ws["acts_a"], B)  # (1, B, ld_a): tanh output, for the tanh' chain
         # dX-only chain through the frozen critic; with scalar Q heads it runs over the samples partitioned by the net that
         # attained min(Q1, Q2): the other net's rows of every dZ are exactly zero (csrc/minnet.h)
         L.check(L.lib.pqlk_dpg_critic_backward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
                                                L.ptr(ws["acts_c"]), L.ptr(ws["dy_c"]), L.ptr(ws["dz_a"]), ws["ld_a"], O, A,
-                                               L.ptr(a_out), ws["ld_a"], L.ptr(ws["bwd_c"]), ws["bwd_c"].numel(), st))
+                                               L.ptr(a_out), ws["ld_a"], C.c_void_p(ws["owner"].data_ptr()) if K == 1 else None,
+                                               L.ptr(ws["bwd_c"]), ws["bwd_c"].numel(), st))
         if tail:
             L.check(L.lib.pqlk_mlp_backward_norm(C.byref(al.desc), L.ptr(self.actor.arena.data), L.ptr(ws["x_obs"]), ws["ld_o"], B,
                                                  L.ptr(ws["acts_a"]), L.ptr(ws["dz_a"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0,

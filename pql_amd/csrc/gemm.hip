@@ -1117,8 +1117,8 @@ extern "C" int64_t pqlk_dpg_backward_ws_floats(const PqlMlpDesc* d, int64_t b) {
 
 extern "C" int pqlk_dpg_critic_backward(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
                                         const float* acts, const float* dy, float* dx, int64_t ld_dx, int32_t dx_col0,
-                                        int32_t dx_cols, const float* dx_tanh_of, int64_t ld_tanh, float* ws, int64_t ws_floats,
-                                        pqlk_stream_t stream) {
+                                        int32_t dx_cols, const float* dx_tanh_of, int64_t ld_tanh, const uint8_t* owner, float* ws,
+                                        int64_t ws_floats, pqlk_stream_t stream) {
   int rc = desc_ok(d);
   if (rc) return rc;
   PQLK_REQUIRE(ws_floats >= pqlk_dpg_backward_ws_floats(d, b), PQLK_E_WORKSPACE);
@@ -1135,10 +1135,10 @@ extern "C" int pqlk_dpg_critic_backward(const PqlMlpDesc* d, const float* params
   int* perm = reinterpret_cast<int*>(ws + 2 * rows_cap * mld);
   int* mn = perm + rows_cap;
   hipStream_t st = pqlk_s(stream);
-  // 1. partition by owning net (+ zero the action-gradient matrix the slice kernel adds into)
+  // 1. partition by owning net
   int64_t q_off, q_ld;
   pqlk_mlp_act_offset(d, b, 0, L - 1, &q_off, &q_ld);
-  hipLaunchKernelGGL(k_minnet_partition, dim3(1), dim3(1024), 0, st, acts + q_off, q_ld, b, perm, rows_cap, mn, dx, b * ld_dx);
+  hipLaunchKernelGGL(k_minnet_partition, dim3(1), dim3(1024), 0, st, owner, acts + q_off, q_ld, b, perm, rows_cap, mn);
   PQLK_LAUNCH_CHECK();
   // 2. head: dZ_{L-1} in compact rows
   {
@@ -1150,6 +1150,7 @@ extern "C" int pqlk_dpg_critic_backward(const PqlMlpDesc* d, const float* params
     h.W = params + w_off; h.sW = net_stride; h.ldk = (int)pqlk_ld(d->dims[L - 1]);
     h.dY = dy; h.sY = b * pqlk_ld(1); h.ldy = (int)pqlk_ld(1);
     h.C = dz[0]; h.perm = perm; h.mn = mn; h.N = 1; h.K = h.ldk; h.rows_cap = rows_cap;
+    h.zero_out = dx; h.zero_floats = b * ld_dx;
     int64_t blocks = rows_cap / 4;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_minnet_head_dx, dim3((unsigned)blocks), dim3(256), (size_t)2 * h.N * h.K * sizeof(float), st, h);

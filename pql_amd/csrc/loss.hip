@@ -210,7 +210,8 @@ extern "C" int pqlk_c51_bce_loss(const float* logits, const float* logits_t, int
 // ------------------------------------------------------------------------------------------------
 // DPG: L = -mean(min(Q1, Q2)); gradient w.r.t. the critic outputs (ties split evenly like torch.min).
 __global__ __launch_bounds__(256) void k_dpg_scalar(const float* __restrict__ q, int64_t ld, int64_t b,
-                                                    float* __restrict__ dy, float* __restrict__ part) {
+                                                    float* __restrict__ dy, float* __restrict__ part,
+                                                    uint8_t* __restrict__ owner) {
   const float g = -1.0f / (float)b;
   float acc = 0.f;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < b; i += (int64_t)gridDim.x * 256) {
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256) void k_dpg_scalar(const float* __restrict__ q,
     const float g2 = c < a ? g : (a == c ? 0.5f * g : 0.f);
     dy[i * ld] = g1;
     dy[(b + i) * ld] = g2;
+    if (owner) owner[i] = (uint8_t)((a <= c ? 1 : 0) | (c <= a ? 2 : 0));   // which net(s) the gradient reaches (minnet.h)
   }
   const float s = block_sum_256(acc);
   if (threadIdx.x == 0) part[blockIdx.x] = s;
@@ -258,9 +260,9 @@ __global__ __launch_bounds__(256) void k_dpg_dist(const float* __restrict__ logi
   if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
-extern "C" int pqlk_dpg_loss(const float* q, int64_t ld, int32_t k, const float* support, int64_t b, float* dy,
-                             float* loss_out, const int32_t* slot_dev, int32_t ring_len, float* scratch,
-                             pqlk_stream_t stream) {
+static int dpg_loss_impl(const float* q, int64_t ld, int32_t k, const float* support, int64_t b, float* dy,
+                         float* loss_out, const int32_t* slot_dev, int32_t ring_len, float* scratch, uint8_t* owner,
+                         pqlk_stream_t stream) {
   PQLK_REQUIRE(q && dy && scratch, PQLK_E_NULL);
   PQLK_REQUIRE(!slot_dev || ring_len > 0, PQLK_E_SHAPE);
   PQLK_REQUIRE(b > 0 && k >= 1, PQLK_E_SHAPE);
@@ -270,7 +272,7 @@ extern "C" int pqlk_dpg_loss(const float* q, int64_t ld, int32_t k, const float*
   if (k == 1) {
     blocks = (int)((b + 255) / 256);
     if (blocks > LOSS_MAX_BLOCKS) blocks = LOSS_MAX_BLOCKS;
-    hipLaunchKernelGGL(k_dpg_scalar, dim3(blocks), dim3(256), 0, pqlk_s(stream), q, ld, b, dy, scratch);
+    hipLaunchKernelGGL(k_dpg_scalar, dim3(blocks), dim3(256), 0, pqlk_s(stream), q, ld, b, dy, scratch, owner);
   } else {
     PQLK_REQUIRE(support, PQLK_E_NULL);
     blocks = (int)((b + 3) / 4);
@@ -283,6 +285,20 @@ extern "C" int pqlk_dpg_loss(const float* q, int64_t ld, int32_t k, const float*
                      slot_dev, (int)ring_len);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
+}
+
+extern "C" int pqlk_dpg_loss(const float* q, int64_t ld, int32_t k, const float* support, int64_t b, float* dy,
+                             float* loss_out, const int32_t* slot_dev, int32_t ring_len, float* scratch,
+                             pqlk_stream_t stream) {
+  return dpg_loss_impl(q, ld, k, support, b, dy, loss_out, slot_dev, ring_len, scratch, nullptr, stream);
+}
+
+// Same; for scalar heads (k == 1) additionally owner[m] = bit 0: the gradient of min(Q1, Q2) reaches net 0, bit 1: net 1
+// (both on an exact tie) -- the input of pqlk_dpg_critic_backward's partition.  owner is not written when k > 1.
+extern "C" int pqlk_dpg_loss_owner(const float* q, int64_t ld, int32_t k, const float* support, int64_t b, float* dy,
+                                   float* loss_out, const int32_t* slot_dev, int32_t ring_len, float* scratch,
+                                   uint8_t* owner, pqlk_stream_t stream) {
+  return dpg_loss_impl(q, ld, k, support, b, dy, loss_out, slot_dev, ring_len, scratch, owner, stream);
 }
 
 // number of per-block loss partials the loss entry points leave in `scratch` (k = 1: scalar heads; k > 1: one wave per row)

@@ -793,21 +793,26 @@ def test_dpg_critic_backward_minnet_matches_dense_chain(dev, hidden, B):
             q[1, :, 0] = q[0, :, 0] - 1.0        # net 1 owns every sample: run 0 is empty
         dy = torch.zeros((2, B, lay.ld_out), device=dev)
         ring = torch.zeros(5, device=dev); slot = torch.zeros(1, dtype=torch.int32, device=dev); scratch = torch.zeros(2048, device=dev)
-        L.check(L.lib.pqlk_dpg_loss(L.ptr(q), lay.ld_out, 1, None, B, L.ptr(dy), L.ptr(ring), L.ptr(slot), 5, L.ptr(scratch), L.stream(dev)))
+        owner = torch.zeros(B, dtype=torch.uint8, device=dev)
+        L.check(L.lib.pqlk_dpg_loss_owner(L.ptr(q), lay.ld_out, 1, None, B, L.ptr(dy), L.ptr(ring), L.ptr(slot), 5, L.ptr(scratch),
+                                          C.c_void_p(owner.data_ptr()), L.stream(dev)))
         outs = []
-        for compact in (False, True):
+        for compact in (False, True, "no_owner"):
             dz = torch.full((1, B, L.ld(A)), 3.0 if compact else 0.0, device=dev)   # the compact path must zero it itself
             if compact:
                 ws = torch.empty(int(L.lib.pqlk_dpg_backward_ws_floats(C.byref(lay.desc), B)), device=dev)
                 L.check(L.lib.pqlk_dpg_critic_backward(C.byref(lay.desc), L.ptr(arena), L.ptr(x), lay.ld_in, B, L.ptr(acts), L.ptr(dy),
-                                                       L.ptr(dz), L.ld(A), O, A, L.ptr(a_out), L.ld(A), L.ptr(ws), ws.numel(), L.stream(dev)))
+                                                       L.ptr(dz), L.ld(A), O, A, L.ptr(a_out), L.ld(A),
+                                                       C.c_void_p(owner.data_ptr()) if compact is True else None,   # NULL: derived from q
+                                                       L.ptr(ws), ws.numel(), L.stream(dev)))
             else:
                 ws = torch.empty(lay.bwd_ws_floats(B, 1), device=dev)
                 L.check(L.lib.pqlk_mlp_backward(C.byref(lay.desc), L.ptr(arena), L.ptr(x), lay.ld_in, B, L.ptr(acts), L.ptr(dy), None, 1,
                                                 L.ptr(dz), L.ld(A), O, A, L.ptr(a_out), L.ld(A), L.ptr(ws), ws.numel(), L.stream(dev)))
             torch.cuda.synchronize()
             outs.append(dz.clone())
-        dense, comp = outs
+        dense, comp, comp_q = outs
         assert float(dense.abs().max()) > 0
         torch.testing.assert_close(comp[0, :, :A], dense[0, :, :A], rtol=2e-5, atol=1e-9 + 2e-6 * float(dense.abs().max()))
         assert torch.all(comp[0, :, A:] == 0)
+        assert torch.equal(comp, comp_q)   # ownership from the byte array == ownership derived from the Q heads
