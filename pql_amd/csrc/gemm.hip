@@ -1122,7 +1122,7 @@ extern "C" int pqlk_dpg_critic_backward(const PqlMlpDesc* d, const float* params
   int rc = desc_ok(d);
   if (rc) return rc;
   PQLK_REQUIRE(ws_floats >= pqlk_dpg_backward_ws_floats(d, b), PQLK_E_WORKSPACE);
-  if (!minnet_ok(d, dx, dx_tanh_of, dx_cols))
+  if (!minnet_ok(d, dx, dx_tanh_of, dx_cols) || b > 131072)   // (the one-block partition holds <= 128 samples per thread)
     return mlp_backward_impl(d, params, x, ldx, b, acts, dy, nullptr, 1, dx, ld_dx, dx_col0, dx_cols, dx_tanh_of, ld_tanh, ws, ws_floats,
                              nullptr, nullptr, stream);
   PQLK_REQUIRE(params && acts && dy && ws, PQLK_E_NULL);

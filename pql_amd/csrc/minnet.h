@@ -28,52 +28,65 @@ __device__ __forceinline__ int minnet_owner(const uint8_t* __restrict__ owner, c
 
 __global__ __launch_bounds__(1024) void k_minnet_partition(const uint8_t* __restrict__ owner, const float* __restrict__ q, int64_t ldq,
                                                            int64_t b, int* __restrict__ perm, int64_t perm_len, int* __restrict__ mn) {
+  // thread t owns the S consecutive samples [t S, (t+1) S): local counts -> wave scan -> wave totals through LDS -> ordered
+  // positions.  Three barriers in all (a chunk-by-chunk ballot scan needed three PER 1024 samples: 13 us at 8192).
   __shared__ int w0[16], w1[16];
-  __shared__ int s_c0, s_c1, s_b0, s_b1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // pass 1: counts
-  int n0 = 0, n1 = 0;
-  for (int64_t m = threadIdx.x; m < b; m += 1024) {
-    const int o = minnet_owner(owner, q, ldq, b, m);
-    n0 += o & 1; n1 += (o >> 1) & 1;
-  }
+  // S = samples per thread, a multiple of 8 so that a thread's owner bytes are whole 8-byte words, all loaded up front (one
+  // byte load at a time, twice over, was 16 dependent-latency round trips: 11 of the kernel's 13 us)
+  constexpr int MAXW = 16;   // up to 128 samples per thread: B <= 131072
+  const int64_t S = ((b + 1023) / 1024 + 7) / 8 * 8;
+  const int64_t m_lo = (int64_t)threadIdx.x * S, m_hi = m_lo + S < b ? m_lo + S : b;
+  const int nw = (int)(S / 8);
+  unsigned long long wv[MAXW];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { n0 += __shfl_xor(n0, o, 64); n1 += __shfl_xor(n1, o, 64); }
-  if (lane == 0) { w0[wave] = n0; w1[wave] = n1; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int a = 0, c = 0;
-    for (int w = 0; w < 16; ++w) { a += w0[w]; c += w1[w]; }
-    s_c0 = a; s_c1 = c; s_b0 = 0; s_b1 = 0;
+  for (int w = 0; w < MAXW; ++w) {
+    wv[w] = 0ull;
+    if (w < nw && m_lo + 8 * w < b) {
+      if (owner && m_lo + 8 * w + 8 <= b) wv[w] = *reinterpret_cast<const unsigned long long*>(owner + m_lo + 8 * w);
+      else
+        for (int j = 0; j < 8; ++j)
+          if (m_lo + 8 * w + j < b) wv[w] |= (unsigned long long)minnet_owner(owner, q, ldq, b, m_lo + 8 * w + j) << (8 * j);
+    }
   }
+  int n0 = 0, n1 = 0;
+#pragma unroll
+  for (int w = 0; w < MAXW; ++w) {
+    n0 += __popcll(wv[w] & 0x0101010101010101ull);
+    n1 += __popcll(wv[w] & 0x0202020202020202ull);
+  }
+  int i0 = n0, i1 = n1;   // inclusive scan over the wave
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t0 = __shfl_up(i0, o, 64), t1 = __shfl_up(i1, o, 64);
+    if (lane >= o) { i0 += t0; i1 += t1; }
+  }
+  if (lane == 63) { w0[wave] = i0; w1[wave] = i1; }
   __syncthreads();
-  const int c0 = s_c0, c1 = s_c1;
+  int e0 = i0 - n0, e1 = i1 - n1, c0 = 0, c1 = 0;   // exclusive prefix of this thread; totals
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) { e0 += w0[w]; e1 += w1[w]; }
+    c0 += w0[w]; c1 += w1[w];
+  }
   const int base1 = (c0 + MN_TILE - 1) / MN_TILE * MN_TILE;
   const int used = base1 + (c1 + MN_TILE - 1) / MN_TILE * MN_TILE;
-  // pad rows of the two runs
-  for (int64_t i = c0 + threadIdx.x; i < base1; i += 1024) perm[i] = -1;
-  for (int64_t i = base1 + c1 + threadIdx.x; i < used && i < perm_len; i += 1024) perm[i] = -1;
-  // pass 2: ordered positions (chunks of 1024 samples, running bases)
-  for (int64_t m0 = 0; m0 < b; m0 += 1024) {
-    const int64_t m = m0 + threadIdx.x;
-    const int o = m < b ? minnet_owner(owner, q, ldq, b, m) : 0;
-    const bool f0 = o & 1, f1 = o & 2;
-    const unsigned long long b0 = __ballot(f0), b1 = __ballot(f1);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (lane == 0) { w0[wave] = __popcll(b0); w1[wave] = __popcll(b1); }
-    __syncthreads();
-    int p0 = s_b0 + __popcll(b0 & below), p1 = s_b1 + __popcll(b1 & below);
-    for (int w = 0; w < wave; ++w) { p0 += w0[w]; p1 += w1[w]; }
-    if (f0) perm[p0] = (int)m;
-    if (f1) perm[base1 + p1] = (int)m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      int a = 0, c = 0;
-      for (int w = 0; w < 16; ++w) { a += w0[w]; c += w1[w]; }
-      s_b0 += a; s_b1 += c;
+#pragma unroll
+  for (int w = 0; w < MAXW; ++w) {
+    if (w < nw) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int o = (int)(wv[w] >> (8 * j)) & 3;
+        const int64_t m = m_lo + 8 * w + j;
+        if (m < m_hi) {
+          if (o & 1) perm[e0++] = (int)m;
+          if (o & 2) perm[base1 + e1++] = (int)m;
+        }
+      }
     }
-    __syncthreads();
   }
+  for (int64_t i = c0 + threadIdx.x; i < base1; i += 1024) perm[i] = -1;                              // pad rows of the two runs
+  for (int64_t i = base1 + c1 + threadIdx.x; i < used && i < perm_len; i += 1024) perm[i] = -1;
   if (threadIdx.x == 0) { mn[0] = c0; mn[1] = c1; mn[2] = base1; mn[3] = used; }
 }
 
