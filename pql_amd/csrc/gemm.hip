@@ -157,7 +157,9 @@ struct Smem {
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
 template <int MODE, int BM, int BN, int EPI, int KT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm(GemmP p) {   // exactly 2 waves per SIMD: the register allocator otherwise aims for 4 and spills the second tile set
+// exactly 2 waves per SIMD (3 for the 128 x 64 tile): the register allocator otherwise aims for 4 and spills the second tile set
+#define PQLK_GEMM_WPE (BM == 128 && BN == 64 ? 3 : 2)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_WPE, PQLK_GEMM_WPE))) void k_gemm(GemmP p) {
   constexpr int WM = BM / 2, WN = BN / 2;  // per-wave patch
   constexpr int MI = WM / 32, NJ = WN / 32;
   constexpr int KC_LD = KT + 4;
@@ -1171,7 +1173,9 @@ extern "C" int pqlk_dpg_critic_backward(const PqlMlpDesc* d, const float* params
     p.ncols_store = p.ldc;
     p.groups = 2; p.zsum = 0; p.epi = EPI_DELU;
     p.perm = perm; p.mn = mn;
-    rc = launch_gemm<MODE_DX, 128, 128, EPI_DELU>(p, 1, st);
+    // 128 x 64 tiles, three blocks per CU: the compact rows are one or two 128-row tiles MORE than b / 128 (each net's run is
+    // padded), so 128 x 128 tiles at two per CU leave a handful of CUs with twice the work (82 -> 63 us on the 512-wide layer)
+    rc = launch_gemm<MODE_DX, 128, 64, EPI_DELU>(p, 1, st);
     if (rc) return rc;
     flip ^= 1;
   }
