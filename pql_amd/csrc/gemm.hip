@@ -568,6 +568,7 @@ static int launch_tile(const GemmP& p, int gz, hipStream_t st) {
   const int ncols = (MODE == MODE_DW) ? p.N : p.ncols_store;
   const long long big = (long long)((p.M + 127) / 128) * ((ncols + 127) / 128) * gz;
 #if !defined(PQLK_FORCE_TILE64)   // tuning switch: everything on 64x64 tiles (more, smaller, better-interleaving blocks)
+  // (128 x 64 tiles at three blocks per CU for the dense products: dX the same, dW 1-2 % slower -- measured, not used)
   if (big >= 256 && ncols >= 128 && EPI != EPI_DTANH_SLICE) return launch_gemm<MODE, 128, 128, EPI>(p, gz, st);
 #endif
   return launch_gemm<MODE, 64, 64, EPI>(p, gz, st);

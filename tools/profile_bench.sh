@@ -40,6 +40,6 @@ if [ "$2" = "full" ]; then
   python3 bench.py --no-cpu-baseline --task Humanoid --batch 32768 --nstep 5 --replay 5000000 --hidden 512,256,128 --steps 200 > $OUT/bench_cfg5.json 2>/dev/null
   python3 bench.py --no-cpu-baseline --task Humanoid --batch 32768 --nstep 5 --replay 5000000 --steps 200 > $OUT/bench_cfg5_hidden512x512x256.json 2>/dev/null
   python3 bench.py --no-cpu-baseline --gpus 2 --layout split2 --share-gpu > $OUT/bench_split2_one_card.json 2>/dev/null
-  python3 bench.py --no-cpu-baseline --gpus 2 --backend gloo --share-gpu --steps 100 > $OUT/bench_dp2_gloo_one_card.json 2>/dev/null
+  python3 bench.py --no-cpu-baseline --gpus 2 --backend gloo --share-gpu --steps 100 2>/dev/null | grep "^{" > $OUT/bench_dp2_gloo_one_card.json
   python3 tools/bench_gather.py cfg2 cfg5 cfg4 > $OUT/gather_sweep.log 2>&1
 fi
