@@ -218,6 +218,39 @@ def gemm_section_ms(v, iters=20):
         return e0.elapsed_time(e1) / iters
 
 
+def dominant_kernel_ms(v, iters=20):
+    """Device time of ONE launch of the dominant kernel -- the fused twin-critic forward `k_mlp_fwd_fused<2,2>` (two per V
+    step, ~38 % of the step) -- measured with HIP events on the stream it is launched on, from a hipGraph of `iters`
+    launches so that host call overhead does not leak into the interval."""
+    from pql_amd import _lib as L
+    from pql_amd.models.mlp import mlp_forward_raw
+    ws = v._workspace(int(v.cfg.algo.batch_size))
+    cl = v.critic.layout
+
+    def one():
+        mlp_forward_raw(cl, v.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"], packed=v.pk_target, stash_all=False)
+
+    with torch.cuda.device(v.device):
+        for _ in range(3):
+            one()
+        side = torch.cuda.Stream(v.device)
+        side.wait_stream(torch.cuda.current_stream(v.device))
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            one()
+        torch.cuda.current_stream(v.device).wait_stream(side)
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                one()
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+
 def gather_ms(v, iters=50):
     """Device time of one fused replay gather launch (HIP events, same stream)."""
     from pql_amd import _lib as L
@@ -489,6 +522,13 @@ def main():
                             "traffic_note": "bytes at the L2<->fabric boundary per V step (FETCH_SIZE x2 + WRITE_SIZE, PMC passes in "
                                             f"{traffic_src}); the family is MFMA-bound, not HBM-bound",
                             "ms_per_launch_group": ms}
+        if v._fused and v.pk_target is not None and v.pk_target.tensor is not None:
+            dms = dominant_kernel_ms(v)
+            f_dom = 2.0 * args.batch * 2 * mlp_macs([O + A] + hidden + [out_c])   # twin critic, forward only
+            line["roofline"]["dominant_kernel"] = {
+                "kernel": "k_mlp_fwd_fused (twin-critic forward incl. the Q head, no stash): one launch",
+                "us_per_launch": dms * 1e3, "gflop_per_launch": f_dom / 1e9, "achieved": f_dom / (dms * 1e-3) / 1e12,
+                "frac": f_dom / (dms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
         gms = gather_ms(v)
         rec_ld = v.memory.ring.rec_ld
         alg_bytes = args.batch * ((2 * O + A) * 4 + 4 + 1 + 8 + (2 * O + A) * 4 + 4 + 4)   # 1557 B/sample @cfg2
@@ -506,6 +546,7 @@ def main():
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
     if pg is not None:
+        barrier()   # the other ranks wait here while rank 0 measures its roofline sections
         torch.distributed.destroy_process_group()
 
 
