@@ -271,6 +271,22 @@ def test_c_abi_reports_argument_errors_as_codes():
     assert lib.pqlk_bn_elu_forward(P, 64, 8, 64, None, None, P, P, 1e-5, 1, 0.1, P, P, P, None) == E_NULL
     assert lib.pqlk_bn_elu_backward(P, P, P, 32, 8, 64, P, P, P, 1e-5, P, None, None, P, None) == E_SHAPE  # ld < cols
     assert lib.pqlk_synth_env_step(0, 8, 2, 1, 0, 1, 0.01, P, P, P, P, None) == E_SHAPE
+    # round-2 entry points: rollout bookkeeping, fused learner tail, min-net DPG backward
+    roll = lambda n, t, obs: lib.pqlk_rollout_step(n, 8, 2, 4, t, obs, P, P, P, P, None, P, P, P, P, P, P, P, P, P, P, P, 100, None)  # noqa: E731
+    assert roll(16, 0, None) == E_NULL
+    assert roll(0, 0, P) == E_SHAPE
+    assert roll(16, 4, P) == E_SHAPE                                                      # t must be < horizon
+    assert roll(16, 0, C.c_void_p(0x1004)) == E_ALIGN                                     # obs_dim % 4 == 0: 16-B rows
+    WS = 6                                                                                # PQLK_E_WORKSPACE
+    assert lib.pqlk_mlp_backward_norm(C.byref(d), P, P, 32, 4, P, P, None, 1, None, 0, 0, 0, None, 0, P, 1 << 20, P, P, None) == E_NULL  # grads
+    assert lib.pqlk_mlp_backward_norm(C.byref(d), P, P, 32, 4, P, P, P, 1, None, 0, 0, 0, None, 0, P, 1 << 20, None, P, None) == E_NULL  # sumsq_part
+    assert lib.pqlk_dpg_critic_backward(C.byref(d), P, P, 32, 4, P, P, P, 32, 6, 2, P, 32, P, P, 8, None) == WS     # workspace too small
+    assert lib.pqlk_dpg_backward_ws_floats(C.byref(d), 0) == 0
+    assert lib.pqlk_dpg_loss_owner(None, 32, 1, None, 4, P, P, None, 1, P, P, None) == E_NULL
+    assert lib.pqlk_dpg_loss_owner(P, 20, 1, None, 4, P, P, None, 1, P, P, None) == E_ALIGN                        # ld % 32
+    assert lib.pqlk_adamw_polyak_fused(None, P, P, P, P, P, None, None, 1.0, 0.5, 5e-4, 0.9, 0.999, 1e-8, 1e-2, 0.05, P, None, P, 8,
+                                       None, 0, 1.0, None, 0, None) == E_NULL
+    assert lib.pqlk_loss_parts(8192, 1) > 0 and lib.pqlk_mlp_norm_parts(C.byref(d)) > 0
     for code in (E_NULL, E_SHAPE, 3, E_ALIGN, E_UNSUPPORTED, 6):
         assert len(lib.pqlk_strerror(code)) > 2
 
