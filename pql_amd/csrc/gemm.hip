@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float dbacc = 0.f;  // DW: column sum of dY for row tid of this block's dW tile (blockIdx.x == 0 only)
+  float dbacc = 0.f;  // DW: partial column sum of dY for row tid % BM of this block's dW tile (blockIdx.x == 0 only)
 
   // two register tile sets of the interior main loop (function scope: declared inside the group loop they are kept in
   // scratch memory instead of registers)
@@ -223,9 +223,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
       const float* sa = smem + stage * S::STAGE;
       const float* sb = sa + S::A_FLOATS;
 
-      if (MODE == MODE_DW && blockIdx.x == 0 && tid < BM) {
-#pragma unroll 8
-        for (int rr = 0; rr < KT; ++rr) dbacc += sa[rr * (BM + 4) + tid];
+      if (MODE == MODE_DW && blockIdx.x == 0) {   // db: thread (column tid % BM, row group tid / BM) sums its rows of the dY stage
+        constexpr int DBR = KT / (256 / BM);      // (all four waves share the work: on wave 0 alone the 16 dependent LDS
+#pragma unroll                                    //  reads per stage held the whole block at the barrier, +5 us on a 26-us GEMM)
+        for (int rr = 0; rr < DBR; ++rr) dbacc += sa[((tid / BM) * DBR + rr) * (BM + 4) + (tid % BM)];
       }
 
 #pragma unroll
@@ -377,6 +378,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
     }
   }
 
+  if (MODE == MODE_DW && blockIdx.x == 0) {   // block-uniform: fold the row groups' partial column sums in group order
+    smem[tid] = dbacc;                        // (the last pipeline stage is no longer read: the k loop ends on a barrier)
+    __syncthreads();
+    if (tid < BM) {
+      dbacc = smem[tid];
+#pragma unroll
+      for (int g = 1; g < 256 / BM; ++g) dbacc += smem[g * BM + tid];
+    }
+    __syncthreads();
+  }
   // ------------------------------------------------------------------------------ epilogue
   // Accumulator layout after the operand swap (the MFMA computes the TRANSPOSED 32x32 tile): lane (r, h) owns output
   // row `.. + r` and, in register quad q = e>>2, the four consecutive columns `.. + 8q + 4h + (e&3)`: every quad is one
