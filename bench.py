@@ -522,7 +522,8 @@ def main():
                             "traffic_note": "bytes at the L2<->fabric boundary per V step (FETCH_SIZE x2 + WRITE_SIZE, PMC passes in "
                                             f"{traffic_src}); the family is MFMA-bound, not HBM-bound",
                             "ms_per_launch_group": ms}
-        if v._fused and v.pk_target is not None and v.pk_target.tensor is not None:
+        # (schedule mode only: the --v-only / --p-only runs are the profiler's per-launch-group passes, tools/pmc_traffic.py)
+        if mode == "schedule" and v._fused and v.pk_target is not None and v.pk_target.tensor is not None:
             dms = dominant_kernel_ms(v)
             f_dom = 2.0 * args.batch * 2 * mlp_macs([O + A] + hidden + [out_c])   # twin critic, forward only
             line["roofline"]["dominant_kernel"] = {
