@@ -164,7 +164,7 @@ def main(cfg):
     if world > 1:
         torch.distributed.destroy_process_group()
     return dict(global_steps=global_steps, critic_updates=v_learner.update_count, actor_updates=p_learner.update_count,
-                rollout_iterations=iter_t + 1, waits=(None if ctl is None else (ctl.sim_wait_time, ctl.critic_wait_time,
+                critic_loss=v_learner.loss_mean(), actor_loss=p_learner.loss_mean(), rollout_iterations=iter_t + 1, waits=(None if ctl is None else (ctl.sim_wait_time, ctl.critic_wait_time,
                                                                                  ctl.actor_wait_time)))
 
 
