@@ -395,6 +395,8 @@ def main():
     split = args.layout == "split2"
     if split and args.gpus != 2:
         raise SystemExit("--layout split2 is the two-GPU placement: use --gpus 2")
+    if args.gpus > 1 and not split and args.share_gpu and args.backend == "nccl":
+        raise SystemExit("--share-gpu puts every rank on cuda:0, which RCCL refuses (duplicate device): add --backend gloo")
     if args.gpus > 1 and not split and "WORLD_SIZE" not in os.environ:
         launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
