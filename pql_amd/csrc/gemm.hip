@@ -156,7 +156,7 @@ struct Smem {
 // magnitude inside the 1e-5 parity bar, and ~6 us cheaper per 8192x512x2 epilogue than libm's expm1f.
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
-template <int MODE, int BM, int BN, int EPI, int KT>
+template <int MODE, int BM, int BN, int EPI, int KT, bool DMA = false>
 // exactly 2 waves per SIMD (3 for the 128 x 64 tile): the register allocator otherwise aims for 4 and spills the second tile set
 #define PQLK_GEMM_WPE (BM == 128 && BN == 64 ? 3 : 2)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_WPE, PQLK_GEMM_WPE))) void k_gemm(GemmP p) {
@@ -165,6 +165,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
   constexpr int KC_LD = KT + 4;
   using S = Smem<MODE, BM, BN, KT>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  // DMA = the LDS stages are filled by global_load_lds_dwordx4 (no VGPR round trip, no ds_write, four stages): unpadded tiles
+  // whose 16-B slots are XOR-swizzled instead (a DMA instruction deposits one contiguous KiB, lane i at +16 i)
+  static_assert(!DMA || MODE != MODE_FWD, "the LDS-DMA main loop serves the backward products");
+  constexpr int SA_F = DMA ? BM * KT : S::A_FLOATS;              // floats of the A part of a stage
+  constexpr int STG_F = DMA ? (BM + BN) * KT : S::STAGE;         // floats per stage
+  constexpr int A_RLD = DMA ? BM : BM + 4, B_RLD = DMA ? BN : BN + 4;   // row stride of a reduction-row tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -220,13 +226,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
 
     // one LDS stage -> MFMAs
     auto compute = [&](int kt, int stage) {
-      const float* sa = smem + stage * S::STAGE;
-      const float* sb = sa + S::A_FLOATS;
+      const float* sa = smem + stage * STG_F;
+      const float* sb = sa + SA_F;
 
       if (MODE == MODE_DW && blockIdx.x == 0) {   // db: thread (column tid % BM, row group tid / BM) sums its rows of the dY stage
         constexpr int DBR = KT / (256 / BM);      // (all four waves share the work: on wave 0 alone the 16 dependent LDS
 #pragma unroll                                    //  reads per stage held the whole block at the barrier, +5 us on a 26-us GEMM)
-        for (int rr = 0; rr < DBR; ++rr) dbacc += sa[((tid / BM) * DBR + rr) * (BM + 4) + (tid % BM)];
+        for (int rr = 0; rr < DBR; ++rr) {
+          const int row = (tid / BM) * DBR + rr;
+          dbacc += sa[row * A_RLD + ((tid % BM) ^ (DMA ? ((row >> 2) & 1) * 32 : 0))];
+        }
       }
 
 #pragma unroll
@@ -247,9 +256,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
         for (int i = 0; i < MI; ++i) {
           if (MODE == MODE_DW) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) af[i][t] = sa[(8 * k8 + 4 * h + t) * (BM + 4) + wm + 32 * i + r];
+            for (int t = 0; t < 4; ++t) af[i][t] = sa[(8 * k8 + 4 * h + t) * A_RLD + ((wm + 32 * i + r) ^ (DMA ? 32 * h : 0))];
           } else {
-            const float4 v = *reinterpret_cast<const float4*>(sa + (wm + 32 * i + r) * KC_LD + 8 * k8 + 4 * h);
+            const float4 v = DMA ? *reinterpret_cast<const float4*>(sa + (wm + 32 * i + r) * KT + 4 * ((2 * k8 + h) ^ ((r >> 2) & 3)))
+                                 : *reinterpret_cast<const float4*>(sa + (wm + 32 * i + r) * KC_LD + 8 * k8 + 4 * h);
             af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
           }
         }
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
             bf[j][0] = v.x; bf[j][1] = v.y; bf[j][2] = v.z; bf[j][3] = v.w;
           } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bf[j][t] = sb[(8 * k8 + 4 * h + t) * (BN + 4) + wn + 32 * j + r];
+            for (int t = 0; t < 4; ++t) bf[j][t] = sb[(8 * k8 + 4 * h + t) * B_RLD + ((wn + 32 * j + r) ^ (DMA ? 32 * h : 0))];
           }
         }
 #endif
@@ -274,6 +284,72 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
       }
     };
 
+    if constexpr (DMA) {
+      // ---- LDS-DMA main loop (launch_gemm picks it when every tile of the grid is interior and nk % 4 == 0).  What the
+      // probes of the register-staged loop below said: its cost is neither the barrier nor the ds_write
+      // but the wave stalling on `vmcnt` before the ds_write -- in order, so it cannot issue MFMAs either -- although the
+      // request ran two tiles ahead.  Here a tile is requested THREE iterations before it is read, straight into the stage
+      // the previous iteration vacated, and costs no VGPRs; a wave only ever waits at the top of an iteration.
+      // Slot maps (16-B slots; lane i of DMA instruction q fills slot 64 q + i of its tile):
+      //   k-contiguous tile (dY of the dX product), rows of KT floats = 4 slots:  slot(row, s) = 4 row + (s ^ ((row >> 2) & 3))
+      //   reduction-row tile, rows of COLS floats:  slot(row, c4) = (COLS / 4) row + (c4 ^ 8 ((row >> 2) & 1))
+      // -> the ds_read_b128 of 16 consecutive rows and the ds_read_b32 of rows k, k + 4 by the two lane halves hit distinct banks.
+      constexpr int AI = BM * KT / 1024, BI = BN * KT / 1024, NI = AI + BI;   // DMA instructions per wave and tile
+      static_assert(BM * KT % 1024 == 0 && BN * KT % 1024 == 0 && KT == 16, "tile does not split into whole-KiB DMA instructions");
+      const int wv = __builtin_amdgcn_readfirstlane(wave);
+      const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+      const float* ga[AI];
+      const float* gb[BI];
+#pragma unroll
+      for (int u = 0; u < AI; ++u) {
+        const int L = 64 * (wv * AI + u) + lane;
+        if (MODE == MODE_DX) {
+          const int row = L >> 2, sl = (L & 3) ^ ((row >> 2) & 3);
+          ga[u] = A + (long long)(m0 + row) * p.lda + kbeg + 4 * sl;
+        } else {
+          const int row = L / (BM / 4), c4 = (L % (BM / 4)) ^ (((row >> 2) & 1) * 8);
+          ga[u] = A + (long long)(kbeg + row) * p.lda + m0 + 4 * c4;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < BI; ++u) {
+        const int L = 64 * (wv * BI + u) + lane;
+        const int row = L / (BN / 4), c4 = (L % (BN / 4)) ^ (((row >> 2) & 1) * 8);
+        gb[u] = B + (long long)(kbeg + row) * p.ldb + n0 + 4 * c4;
+      }
+      const long long a_step = (MODE == MODE_DX) ? (long long)KT : (long long)KT * p.lda, b_step = (long long)KT * p.ldb;
+      int issued = 0;   // tiles requested so far; past the last one the tail re-requests it into a stage nobody reads again
+#define PQLK_DMA(STG)                                                                                                          \
+  do {                                                                                                                         \
+    _Pragma("unroll") for (int u = 0; u < AI; ++u)                                                                             \
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"                                           \
+                   ::"s"(lds0 + 4u * ((STG) * STG_F) + 1024u * (wv * AI + u)), "v"(ga[u]) : "memory");                         \
+    _Pragma("unroll") for (int u = 0; u < BI; ++u)                                                                             \
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"                                           \
+                   ::"s"(lds0 + 4u * ((STG) * STG_F + SA_F) + 1024u * (wv * BI + u)), "v"(gb[u]) : "memory");                   \
+    ++issued;                                                                                                                  \
+    const long long as_ = issued < nk ? a_step : 0, bs_ = issued < nk ? b_step : 0;                                            \
+    _Pragma("unroll") for (int u = 0; u < AI; ++u) ga[u] += as_;                                                               \
+    _Pragma("unroll") for (int u = 0; u < BI; ++u) gb[u] += bs_;                                                               \
+  } while (0)
+      // wait until at most two tiles' worth of this wave's requests are outstanding (vmcnt only; expcnt / lgkmcnt untouched)
+#define PQLK_DMA_WAIT(N) __builtin_amdgcn_s_waitcnt(((N) & 0xF) | 0x70 | 0xF00 | ((((N) >> 4) & 3) << 14))
+      __syncthreads();  // previous group's stages may still be in use
+      PQLK_DMA(0);
+      PQLK_DMA(1);
+      PQLK_DMA(2);
+      for (int kt = 0; kt < nk; kt += 4) {
+        PQLK_DMA_WAIT(2 * NI); __syncthreads(); PQLK_DMA(3); compute(kt, 0);
+        PQLK_DMA_WAIT(2 * NI); __syncthreads(); PQLK_DMA(0); compute(kt + 1, 1);
+        PQLK_DMA_WAIT(2 * NI); __syncthreads(); PQLK_DMA(1); compute(kt + 2, 2);
+        PQLK_DMA_WAIT(2 * NI); __syncthreads(); PQLK_DMA(2); compute(kt + 3, 3);
+      }
+      PQLK_DMA_WAIT(0);
+      __syncthreads();   // the tail's re-requests have landed and every wave is done reading: LDS is free for the epilogue
+#undef PQLK_DMA
+#undef PQLK_DMA_WAIT
+      continue;
+    }
 #if !defined(PQLK_PROBE_NOLOAD) && !defined(PQLK_NO_PF2)
     // ---- interior blocks: every tile is full, so the loads need no bounds tests, are straight-line code, and can run TWO
     // tiles ahead: tile kt+2 is requested at the top of iteration kt into the register set that tile kt vacated, tile kt+1
@@ -306,18 +382,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
       PQLK_SS(0, 0);
       PQLK_GL(1, 1);
       __syncthreads();
+#if defined(PQLK_PROBE_NOBAR)   // tuning probes only (wrong results): the k loop without its barriers / global requests / LDS stores
+#define PQLK_BAR() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PQLK_BAR() __syncthreads()
+#endif
+#if defined(PQLK_PROBE_NOGL)
+#define PQLK_GLP(KTILE, Q) (void)0
+#else
+#define PQLK_GLP(KTILE, Q) PQLK_GL(KTILE, Q)
+#endif
+#if defined(PQLK_PROBE_NOSS)
+#define PQLK_SSP(STG, Q) (void)0
+#else
+#define PQLK_SSP(STG, Q) PQLK_SS(STG, Q)
+#endif
       for (int kt = 0; kt < nk; kt += 2) {
-        PQLK_GL(min(kt + 2, nk - 1), 0);
+        PQLK_GLP(min(kt + 2, nk - 1), 0);
         __builtin_amdgcn_sched_barrier(0);   // keep the requests at the top of the iteration
         compute(kt, 0);
-        PQLK_SS(1, 1);
-        __syncthreads();
-        PQLK_GL(min(kt + 3, nk - 1), 1);
+        PQLK_SSP(1, 1);
+        PQLK_BAR();
+        PQLK_GLP(min(kt + 3, nk - 1), 1);
         __builtin_amdgcn_sched_barrier(0);
         compute(kt + 1, 1);
-        PQLK_SS(0, 0);
-        __syncthreads();
+        PQLK_SSP(0, 0);
+        PQLK_BAR();
       }
+#undef PQLK_BAR
+#undef PQLK_GLP
+#undef PQLK_SSP
 #undef PQLK_GL
 #undef PQLK_SS
       continue;
@@ -548,6 +642,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
     }
 }
 
+// PQLK_GEMM_DMA=0 keeps every GEMM on the register-staged main loop (A/B switch of the LDS-DMA loop; read once)
+static bool gemm_dma_enabled() {
+  static const bool on = [] { const char* e = getenv("PQLK_GEMM_DMA"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <int MODE, int BM, int BN, int EPI>
 static int launch_gemm(GemmP p, int gz, hipStream_t st) {
   constexpr int KT = PQLK_KT;
@@ -568,6 +668,27 @@ static int launch_gemm(GemmP p, int gz, hipStream_t st) {
     ncols = p.col0 + p.ncol - p.n_base;
   }
   dim3 grid((unsigned)((ncols + BN - 1) / BN), (unsigned)((p.M + BM - 1) / BM), (unsigned)gz);
+  if constexpr (KT == 16 && (MODE == MODE_DX || MODE == MODE_DW) && (EPI == EPI_DELU || EPI == EPI_NONE)) {
+    // LDS-DMA main loop: every tile of the grid interior, whole 16-deep stages in multiples of four, 16-B aligned operands
+    bool dma = gemm_dma_enabled() && p.M % BM == 0 && ncols % BN == 0 && p.N % BN == 0 && !p.C2 && pqlk_aligned16(p.A) &&
+               pqlk_aligned16(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0;
+    if (MODE == MODE_DX) dma = dma && p.K % (4 * KT) == 0 && p.K <= p.lda && ncols <= p.ldb && p.sA % 4 == 0 && p.sB % 4 == 0;
+    else dma = dma && p.rows_per_split % (4 * KT) == 0 && p.K % p.rows_per_split == 0 && p.K / p.rows_per_split == p.splits &&
+               p.M <= p.lda && p.N <= p.ldb && p.sA % 4 == 0 && p.sB % 4 == 0;
+    if (dma) {
+      constexpr size_t dma_floats = (size_t)4 * (BM + BN) * KT;
+      const size_t dshmem = (dma_floats > patch_floats ? dma_floats : patch_floats) * sizeof(float);
+      static PqlkPerDeviceOnce dma_once;
+      if (dma_once.need()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, BM, BN, EPI, KT, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dshmem);
+        if (e != hipSuccess) return -(int)e;
+      }
+      hipLaunchKernelGGL((k_gemm<MODE, BM, BN, EPI, KT, true>), grid, dim3(256), dshmem, st, p);
+      PQLK_LAUNCH_CHECK();
+      return PQLK_OK;
+    }
+  }
   hipLaunchKernelGGL((k_gemm<MODE, BM, BN, EPI, KT>), grid, dim3(256), shmem, st, p);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
