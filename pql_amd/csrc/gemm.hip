@@ -54,6 +54,7 @@ struct GemmP {
   // net's weights (B) and activations (aux, row perm[i]); tiles past mn[3] exit at once.
   const int* perm;
   const int* mn;
+  int xcd_remap;      // set by launch_gemm when the grid divides into whole groups per XCD
 };
 
 #include "narrow.h"
@@ -176,7 +177,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
-  const int m0 = blockIdx.y * BM, n0 = p.n_base + blockIdx.x * BN;
+  // XCD-aware tile order.  Workgroups go to the 8 XCDs round robin in dispatch order (x fastest), so the tiles that share an
+  // operand -- the column tiles of one row tile (dX / forward: the same rows of A), all tiles of one (net, batch split) of a dW
+  // product (the same rows of dY and X) -- would sit under 8 different L2s and each fetch the operand across the fabric.
+  // Re-label: dispatch slot w lands on XCD w % 8; give that XCD whole groups of G sharing tiles, G consecutive slots each.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_remap) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int G = (MODE == MODE_DW) ? gx * gy : gx;
+    const int w = bx + gx * (by + gy * bz), sl = w >> 3;
+    const int L = ((sl / G) * 8 + (w & 7)) * G + sl % G;
+    bx = L % gx; by = (L / gx) % gy; bz = L / (gx * gy);
+  }
+  const int m0 = by * BM, n0 = p.n_base + bx * BN;
 
   int g0 = 0, g1 = 1, split = 0;
   if (MODE == MODE_DX && p.perm) {   // compact rows: one net per row tile (sA = sC = 0, grid.z = 1 on the host side)
@@ -184,14 +197,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
     g0 = m0 >= p.mn[2] ? 1 : 0;
     g1 = g0 + 1;
   } else if (MODE == MODE_DW) {
-    g0 = blockIdx.z / p.splits;
-    split = blockIdx.z % p.splits;
+    g0 = bz / p.splits;
+    split = bz % p.splits;
     g1 = g0 + 1;
   } else if (MODE == MODE_DX && p.zsum) {
     g0 = 0;
     g1 = p.groups;
   } else {
-    g0 = blockIdx.z;
+    g0 = bz;
     g1 = g0 + 1;
   }
 
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  float dbacc = 0.f;  // DW: partial column sum of dY for row tid % BM of this block's dW tile (blockIdx.x == 0 only)
+  float dbacc = 0.f;  // DW: partial column sum of dY for row tid % BM of this block's dW tile (bx == 0 only)
 
   // two register tile sets of the interior main loop (function scope: declared inside the group loop they are kept in
   // scratch memory instead of registers)
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
       const float* sa = smem + stage * STG_F;
       const float* sb = sa + SA_F;
 
-      if (MODE == MODE_DW && blockIdx.x == 0) {   // db: thread (column tid % BM, row group tid / BM) sums its rows of the dY stage
+      if (MODE == MODE_DW && bx == 0) {   // db: thread (column tid % BM, row group tid / BM) sums its rows of the dY stage
         constexpr int DBR = KT / (256 / BM);      // (all four waves share the work: on wave 0 alone the 16 dependent LDS
 #pragma unroll                                    //  reads per stage held the whole block at the barrier, +5 us on a 26-us GEMM)
         for (int rr = 0; rr < DBR; ++rr) {
@@ -472,7 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
     }
   }
 
-  if (MODE == MODE_DW && blockIdx.x == 0) {   // block-uniform: fold the row groups' partial column sums in group order
+  if (MODE == MODE_DW && bx == 0) {   // block-uniform: fold the row groups' partial column sums in group order
     smem[tid] = dbacc;                        // (the last pipeline stage is no longer read: the k loop ends on a barrier)
     __syncthreads();
     if (tid < BM) {
@@ -532,7 +545,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
         }
         if (i + 1 < MI) __syncthreads();
       }
-      if (MODE == MODE_DW && blockIdx.x == 0 && tid < BM && p.dbias) {
+      if (MODE == MODE_DW && bx == 0 && tid < BM && p.dbias) {
         float* db = p.dbias + (long long)g0 * p.sBias + (long long)split * p.sSplit;
         const int row = m0 + tid;
         if (row < p.ncols_store) db[row] = row < p.M ? dbacc : 0.f;
@@ -555,7 +568,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
                 make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
         }
       }
-    if (blockIdx.x == 0 && tid < BM && p.dbias) {
+    if (bx == 0 && tid < BM && p.dbias) {
       float* db = p.dbias + (long long)g0 * p.sBias + (long long)split * p.sSplit;
       const int row = m0 + tid;
       if (row < p.ncols_store) db[row] = row < p.M ? dbacc : 0.f;  // ncols_store = pqlk_ld(out): zero bias pad
@@ -648,6 +661,11 @@ static bool gemm_dma_enabled() {
   return on;
 }
 
+static bool gemm_xcd_enabled() {   // PQLK_GEMM_XCD=0: dispatch-order tiles (A/B switch of the XCD-aware order; read once)
+  static const bool on = [] { const char* e = getenv("PQLK_GEMM_XCD"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <int MODE, int BM, int BN, int EPI>
 static int launch_gemm(GemmP p, int gz, hipStream_t st) {
   constexpr int KT = PQLK_KT;
@@ -668,6 +686,10 @@ static int launch_gemm(GemmP p, int gz, hipStream_t st) {
     ncols = p.col0 + p.ncol - p.n_base;
   }
   dim3 grid((unsigned)((ncols + BN - 1) / BN), (unsigned)((p.M + BM - 1) / BM), (unsigned)gz);
+  {
+    const long long tiles = (long long)grid.x * grid.y * grid.z, group = (MODE == MODE_DW) ? (long long)grid.x * grid.y : grid.x;
+    p.xcd_remap = gemm_xcd_enabled() && tiles % (8 * group) == 0 && tiles < (1LL << 30);
+  }
   if constexpr (KT == 16 && (MODE == MODE_DX || MODE == MODE_DW) && (EPI == EPI_DELU || EPI == EPI_NONE)) {
     // LDS-DMA main loop: every tile of the grid interior, whole 16-deep stages in multiples of four, 16-B aligned operands
     bool dma = gemm_dma_enabled() && p.M % BM == 0 && ncols % BN == 0 && p.N % BN == 0 && !p.C2 && pqlk_aligned16(p.A) &&
