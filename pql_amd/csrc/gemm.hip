@@ -225,6 +225,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
   KcTile<BN, KT> b_kc0, b_kc1;
   RrTile<BN, KT> b_rr0, b_rr1;
 
+  // ELU' operand of the dX epilogue, requested before the k loop (LDS-DMA instantiations only: the register-staged loop has no
+  // VGPRs to spare -- 247 of 256 -- and spilled when this was tried there).  Same (row, 4-column) ownership as the epilogue's
+  // row-wise pass; the requests are older than every DMA request, so the loop's first counted wait retires them.
+  constexpr int PF_LPR = WN / 4, PF_RPI = 64 / PF_LPR, PF_N = 32 / PF_RPI;
+  constexpr bool AUX_PF = DMA && MODE == MODE_DX && EPI == EPI_DELU;
+  f4v hpre[AUX_PF ? MI : 1][AUX_PF ? PF_N : 1];
+  if constexpr (AUX_PF) {
+    const float* auxw = p.aux + (long long)g0 * p.sAux;
+    const int prow = lane / PF_LPR, pc4 = lane % PF_LPR;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int it = 0; it < PF_N; ++it) {
+        const long long grow = m0 + wm + 32 * i + it * PF_RPI + prow;
+        long long arow = grow;
+        if (p.perm) { const int pr = p.perm[grow]; arow = pr < 0 ? 0 : pr; }   // pad rows: dZ is zero anyway
+        hpre[i][it] = *reinterpret_cast<const f4v*>(auxw + arow * p.ldaux + n0 + wn + 4 * pc4);
+      }
+  }
+
   for (int g = g0; g < g1; ++g) {
     const float* A = p.A + (long long)g * p.sA;
     const float* B = p.B + (long long)g * p.sB;
@@ -533,9 +553,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
           const long long grow = m0 + wm + 32 * i + rr;
           const int gcol = n0 + wn + 4 * pc4;
           if (EPI == EPI_DELU) {
-            long long arow = grow;
-            if (MODE == MODE_DX && p.perm) { const int pr = p.perm[grow]; arow = pr < 0 ? 0 : pr; }   // pad rows: dZ is zero anyway
-            const float4 h4 = *reinterpret_cast<const float4*>(auxw + arow * p.ldaux + gcol);
+            float4 h4;
+            if constexpr (AUX_PF) {
+              h4 = make_float4(hpre[i][it].x, hpre[i][it].y, hpre[i][it].z, hpre[i][it].w);
+            } else {
+              long long arow = grow;
+              if (MODE == MODE_DX && p.perm) { const int pr = p.perm[grow]; arow = pr < 0 ? 0 : pr; }   // pad rows: dZ is zero anyway
+              h4 = *reinterpret_cast<const float4*>(auxw + arow * p.ldaux + gcol);
+            }
             v.x = h4.x > 0.f ? v.x : v.x * (h4.x + 1.f);  // ELU'(x) = exp(x) = elu(x) + 1 for x <= 0
             v.y = h4.y > 0.f ? v.y : v.y * (h4.y + 1.f);
             v.z = h4.z > 0.f ? v.z : v.z * (h4.z + 1.f);
@@ -693,7 +718,7 @@ static int launch_gemm(GemmP p, int gz, hipStream_t st) {
   if constexpr (KT == 16 && (MODE == MODE_DX || MODE == MODE_DW) && (EPI == EPI_DELU || EPI == EPI_NONE)) {
     // LDS-DMA main loop: every tile of the grid interior, whole 16-deep stages in multiples of four, 16-B aligned operands
     bool dma = gemm_dma_enabled() && p.M % BM == 0 && ncols % BN == 0 && p.N % BN == 0 && !p.C2 && pqlk_aligned16(p.A) &&
-               pqlk_aligned16(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0;
+               pqlk_aligned16(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0 && (EPI != EPI_DELU || (p.aux && pqlk_aligned16(p.aux) && p.ldaux % 4 == 0));
     if (MODE == MODE_DX) dma = dma && p.K % (4 * KT) == 0 && p.K <= p.lda && ncols <= p.ldb && p.sA % 4 == 0 && p.sB % 4 == 0;
     else dma = dma && p.rows_per_split % (4 * KT) == 0 && p.K % p.rows_per_split == 0 && p.K / p.rows_per_split == p.splits &&
                p.M <= p.lda && p.N <= p.ldb && p.sA % 4 == 0 && p.sB % 4 == 0;
