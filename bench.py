@@ -209,10 +209,21 @@ def gemm_section_ms(v, iters=20):
     with torch.cuda.device(v.device):
         for _ in range(3):
             section()
+        # replayed from a hipGraph, like the learner's own step: the interval then holds device time only (launched eagerly,
+        # a host hiccup between two of the 140 ctypes calls shows up as GPU idle time inside the HIP-event interval)
+        side = torch.cuda.Stream(v.device)
+        side.wait_stream(torch.cuda.current_stream(v.device))
+        with torch.cuda.stream(side):
+            section()
+        torch.cuda.current_stream(v.device).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(iters):
+                section()
+        g.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(iters):
-            section()
+        g.replay()
         e1.record()
         e1.synchronize()
         return e0.elapsed_time(e1) / iters

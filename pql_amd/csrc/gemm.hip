@@ -60,6 +60,12 @@ struct GemmP {
 #include "narrow.h"
 #include "minnet.h"
 
+#ifndef PQLK_PROBE_DMA_A   // tuning probes only (wrong results): leave one operand's DMA requests out of the k loop
+#define PQLK_PROBE_DMA_A true
+#endif
+#ifndef PQLK_PROBE_DMA_B
+#define PQLK_PROBE_DMA_B true
+#endif
 #define KT_MAX 32   // reduction elements per LDS stage (template parameter KT: 32 or 16)
 #ifndef PQLK_KT
 #define PQLK_KT 16   // 16: half the LDS per block -> a third block per CU; +3 % on the streamed learner step vs 32
@@ -355,9 +361,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
 #define PQLK_DMA(STG)                                                                                                          \
   do {                                                                                                                         \
     _Pragma("unroll") for (int u = 0; u < AI; ++u)                                                                             \
+      if (PQLK_PROBE_DMA_A)                                                                                                    \
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"                                           \
                    ::"s"(lds0 + 4u * ((STG) * STG_F) + 1024u * (wv * AI + u)), "v"(ga[u]) : "memory");                         \
     _Pragma("unroll") for (int u = 0; u < BI; ++u)                                                                             \
+      if (PQLK_PROBE_DMA_B)                                                                                                    \
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"                                           \
                    ::"s"(lds0 + 4u * ((STG) * STG_F + SA_F) + 1024u * (wv * BI + u)), "v"(gb[u]) : "memory");                   \
     ++issued;                                                                                                                  \
