@@ -129,6 +129,8 @@ __device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, in
   const bool active = t0 < ntiles;   // wave-uniform
   const float4* lds4 = reinterpret_cast<const float4*>(fsm);
   FP_TICK(0);
+  // (a stagger of the SIMD partners -- waves 4-7 entering each layer 256 / 512 / 1024 cycles behind waves 0-3 -- measured
+  //  +0.5 / 0 / -0.3 % on the V step, inside the noise: not used)
   // Deferred stash: this layer's INPUT buffer is the previous layer's output.  Writing it to HBM from here, spread over
   // the main loop (thread tid takes float4 elements tid, tid + 512, ... of the (32 R) x nprev tile: whole 1 KiB lines per
   // wave instruction), replaces the epilogue's burst of 32-B-per-row stores that every block issues at the same moment
