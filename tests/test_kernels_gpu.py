@@ -816,3 +816,56 @@ def test_dpg_critic_backward_minnet_matches_dense_chain(dev, hidden, B):
         torch.testing.assert_close(comp[0, :, :A], dense[0, :, :A], rtol=2e-5, atol=1e-9 + 2e-6 * float(dense.abs().max()))
         assert torch.all(comp[0, :, A:] == 0)
         assert torch.equal(comp, comp_q)   # ownership from the byte array == ownership derived from the Q heads
+
+
+_GEMM_LOOP_SCRIPT = r"""
+import ctypes as C, hashlib, sys
+sys.path.insert(0, {tests!r}); sys.path.insert(0, {root!r})
+import numpy as np, torch
+import detdata as dd
+from pql_amd import _lib as L
+from pql_amd.models.mlp import ArenaLayout, PackedWeights, default_splits, mlp_forward_raw
+dev = torch.device("cuda:0")
+out = []
+for dims, nets, B in (([104, 512, 512, 256, 1], 2, 8192), ([88, 512, 256, 128, 16], 1, 4096), ([232, 512, 512, 256, 51], 2, 2048)):
+    lay = ArenaLayout(dims, nets)
+    arena = torch.zeros(lay.total, device=dev)
+    for n in range(nets):
+        for l in range(lay.n_layers):
+            lay.weight(arena, n, l).copy_(torch.from_numpy(dd.uniform((dims[l + 1], dims[l]), 40 * n + l, -0.05, 0.05)))
+            lay.bias(arena, n, l).copy_(torch.from_numpy(dd.uniform((dims[l + 1],), 40 * n + l + 20, -0.05, 0.05)))
+    x = torch.zeros((B, lay.ld_in), device=dev); x[:, :dims[0]] = torch.from_numpy(dd.uniform((B, dims[0]), 4243, -1, 1)).to(dev)
+    pk = PackedWeights(lay, dev); pk.refresh(arena)
+    acts = mlp_forward_raw(lay, arena, x, L.ACT_NONE, packed=pk, stash_all=True)
+    dy = torch.zeros((nets, B, lay.ld_out), device=dev)
+    dy[:, :, :dims[-1]] = torch.from_numpy(dd.uniform((nets, B, dims[-1]), 4244, -1e-3, 1e-3)).to(dev)
+    splits = default_splits(B)
+    grads = torch.empty_like(arena); dx = torch.empty((B, lay.ld_in), device=dev)
+    ws = torch.empty(lay.bwd_ws_floats(B, splits), device=dev)
+    L.check(L.lib.pqlk_mlp_backward(C.byref(lay.desc), L.ptr(arena), L.ptr(x), lay.ld_in, B, L.ptr(acts), L.ptr(dy), L.ptr(grads), splits,
+                                    L.ptr(dx), lay.ld_in, 0, 0, None, 0, L.ptr(ws), ws.numel(), L.stream(dev)))
+    torch.cuda.synchronize()
+    assert torch.isfinite(grads).all() and grads.abs().max() > 0
+    out.append(hashlib.sha256(grads.cpu().numpy().tobytes() + dx.cpu().numpy().tobytes()).hexdigest())
+print(" ".join(out))
+"""
+
+
+def test_gemm_lds_dma_loop_is_bitwise_the_register_staged_loop(dev):
+    """The backward GEMMs take the LDS-DMA main loop when every tile of the grid is interior and the register-staged one
+    otherwise (gemm.hip, launch_gemm).  Same reduction order by construction; here: the gradients and the input gradient of
+    three BASELINE-shaped MLPs hash identically with the DMA loop on and with PQLK_GEMM_DMA=0 / PQLK_GEMM_XCD=0 (the
+    switches are read once per process, hence the subprocesses)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _GEMM_LOOP_SCRIPT.format(tests=os.path.join(root, "tests"), root=root)
+    hashes = {}
+    for name, extra in (("dma+xcd", {}), ("staged", {"PQLK_GEMM_DMA": "0"}), ("dma, dispatch order", {"PQLK_GEMM_XCD": "0"})):
+        env = dict(os.environ, **extra)
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        hashes[name] = r.stdout.strip().split()
+    assert len(hashes["dma+xcd"]) == 3
+    assert hashes["dma+xcd"] == hashes["staged"] == hashes["dma, dispatch order"], hashes
