@@ -526,6 +526,11 @@ def main():
         if tpaths and args.hidden == "512,512,256" and args.task == "AllegroHand" and args.batch == 8192:
             traffic = json.load(open(tpaths[-1]))
             traffic_src = os.path.relpath(tpaths[-1], ROOT)
+        mfma_util, mfma_src = None, None
+        mpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_mfma.json")))   # committed matrix-pipe counter pass; newest tag
+        if mpaths and traffic_src is not None:
+            mfma_util = {k: round(v["mfma_util"], 3) for k, v in json.load(open(mpaths[-1]))["kernels"].items()}
+            mfma_src = os.path.relpath(mpaths[-1], ROOT)
         # roofline of the dominant kernel family: the fp32-MFMA GEMMs of one V step (k_gemm<...>)
         ms = gemm_section_ms(v)
         achieved = f_v / (ms * 1e-3) / 1e12
@@ -534,7 +539,9 @@ def main():
                             "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("mfma_family_per_v_step_bytes"),
                             "traffic_note": "bytes at the L2<->fabric boundary per V step (FETCH_SIZE x2 + WRITE_SIZE, PMC passes in "
                                             f"{traffic_src}); the family is MFMA-bound, not HBM-bound",
-                            "ms_per_launch_group": ms}
+                            "ms_per_launch_group": ms,
+                            "mfma_util": mfma_util,
+                            "mfma_util_note": f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) per kernel, counter pass in {mfma_src}"}
         # (schedule mode only: the --v-only / --p-only runs are the profiler's per-launch-group passes, tools/pmc_traffic.py)
         if mode == "schedule" and v._fused and v.pk_target is not None and v.pk_target.tensor is not None:
             dms = dominant_kernel_ms(v)

@@ -4,8 +4,8 @@
 #   sched   the headline 1:4:8 schedule, three HIP streams (per-kernel averages include cross-stream contention)
 #   v_only  the V-learner alone on ONE stream (--no-streams): every kernel's average is contention-free
 #   p_only  the P-learner alone on ONE stream
-# and, with `full`, the two PMC passes (FETCH_SIZE / WRITE_SIZE, kernel-trace only, separate runs) reduced by
-# tools/pmc_traffic.py, plus un-profiled bench lines for the other BASELINE shapes.
+# and, with `full`, the PMC passes (FETCH_SIZE / WRITE_SIZE / matrix-pipe busy cycles: kernel-trace only, separate runs) reduced by
+# tools/pmc_traffic.py and tools/pmc_mfma.py, plus un-profiled bench lines for the other BASELINE shapes.
 # Outputs land in gpurun_out/<tag>/; copy what should be judged into profiles/.
 set -e
 TAG=${1:-prof}
@@ -33,6 +33,11 @@ if [ "$2" = "full" ]; then
   F=$(pmc FETCH_SIZE); W=$(pmc WRITE_SIZE)
   python3 tools/pmc_traffic.py "$F" "$W" $OUT/pmc_traffic.json > /dev/null
   rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+  # matrix-pipe utilisation per kernel (a third counter pass, kernel-trace only)
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o pmc -- python3 bench.py \
+      --steps 48 --warmup 16 --no-cpu-baseline --no-streams --v-only --repeat 1 > /dev/null 2> $OUT/pmc_mfma.err || tail -5 $OUT/pmc_mfma.err
+  python3 tools/pmc_mfma.py "$(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1)" $OUT/pmc_mfma.json > /dev/null
+  rm -rf $OUT/pmc_mfma
   python3 bench.py --steps 800 --warmup 96 > $OUT/bench.json 2> $OUT/bench.err
   python3 bench.py --no-cpu-baseline --hidden 512,256,128 > $OUT/bench_hidden_ref.json 2>/dev/null
   python3 bench.py --no-cpu-baseline --task ShadowHand --num-envs 16384 --distl --replay 2000000 --hidden 512,256,128 > $OUT/bench_cfg4.json 2>/dev/null
