@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--hidden", default="512,512,256", help="BASELINE shape; the reference default is 512,256,128")
     ap.add_argument("--distl", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph-rng", action="store_true", help="capture the learners' RNG draws inside their hipGraphs (A/B; default: in front)")
     ap.add_argument("--no-streams", action="store_true", help="serialise V / P / rollout on one stream")
     ap.add_argument("--no-fused", action="store_true", help="per-layer GEMM launches instead of the fused hidden-layer forward")
     ap.add_argument("--no-fused-tail", action="store_true", help="separate loss-fold / gradient-norm launches (A/B of algo.fused_tail)")
@@ -93,7 +94,7 @@ def build_system(args, rank, world, device, pg, learner_device=None):
           f"algo.memory_size={args.replay}", f"algo.nstep={args.nstep}", f"algo.distl={args.distl}",
           f"algo.v_learner_gpu={(learner_device or device).index}", f"algo.p_learner_gpu={(learner_device or device).index}",
           f"algo.num_gpus={1 if learner_device is None else 2}",
-          f"algo.graph={not args.no_graph}", f"algo.streams={not args.no_streams}", f"algo.fused={not args.no_fused}", f"sim_device=cuda:{device.index}",
+          f"algo.graph={not args.no_graph}", f"algo.graph_rng={bool(getattr(args, 'graph_rng', False))}", f"algo.streams={not args.no_streams}", f"algo.fused={not args.no_fused}", f"sim_device=cuda:{device.index}",
           f"device=cuda:{device.index}"]
     cfg = load_cfg(ov)
     cfg.algo.hidden_layers = hidden

@@ -69,6 +69,7 @@ class PQLPLearner:
         self.normalize_tuple = None
         self.sleep_time = 0.01
         self.use_graph = bool(_cfg_get(algo, "graph", False))
+        self._graph_rng = bool(_cfg_get(algo, "graph_rng", False))   # False: the randint is issued in front of the graph
         self.stream = torch.cuda.Stream(self.device) if bool(_cfg_get(algo, "streams", False)) else None
         # start()/update() hand out double-buffered snapshots of the actor (a pickled copy in the reference)
         self._pub = H.ArenaPublisher(self.actor)
@@ -201,8 +202,12 @@ class PQLPLearner:
         apply_optimizer(self.actor.arena.data, ws["grads"], self.opt, None, algo.actor_lr, algo.max_grad_norm, 0.0,
                         1.0 / self.world, self.device, layout=self.actor.layout, packed=self.pk_actor)
 
-    def _draw_and_step(self, ws, upto_backward=False):
+    def _draws(self, ws):
         torch.randint(self.cur_capacity, (ws["B"],), generator=self.gen, out=ws["idx"])  # the only draw (:49), no copy launch
+
+    def _draw_and_step(self, ws, upto_backward=False, draw=True):
+        if draw:
+            self._draws(ws)
         self._step_kernels(ws, ws["idx"], upto_backward)
 
     @torch.no_grad()
@@ -220,10 +225,12 @@ class PQLPLearner:
                 H.release(lease, st)
                 self._step_kernels(ws, ws["idx"])
             elif self.use_graph:
-                key = (B, self.cur_capacity, id(self.critic), self.normalize_tuple is None)
+                key = (B, self.cur_capacity if self._graph_rng else 0, id(self.critic), self.normalize_tuple is None)
                 if self._graph is None or self._graph_key != key:
                     with H.CAPTURE_LOCK:
                         self._capture(ws, key)
+                if not self._graph_rng:   # draws in front of the graph (see PQLVLearner.__init__)
+                    self._draws(ws)
                 self._graph.replay()
                 if self._graph_post is not None:
                     self._allreduce_grads(ws)
@@ -238,7 +245,7 @@ class PQLPLearner:
 
     def _new_graph(self):
         g = torch.cuda.CUDAGraph()
-        if self.gen is not None:
+        if self.gen is not None and self._graph_rng:
             g.register_generator_state(self.gen)
         return g
 
@@ -268,10 +275,10 @@ class PQLPLearner:
         # ONE graph instead of splitting the step around an eager collective
         if not self.dp or graph_collective_enabled(self.pg):
             with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
-                self._draw_and_step(ws)
+                self._draw_and_step(ws, draw=self._graph_rng)
         else:
             with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
-                self._draw_and_step(ws, upto_backward=True)
+                self._draw_and_step(ws, upto_backward=True, draw=self._graph_rng)
             g_post = self._new_graph()
             with torch.cuda.graph(g_post, stream=self._capture_stream, capture_error_mode="thread_local"):
                 self._step_post(ws)

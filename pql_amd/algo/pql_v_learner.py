@@ -253,6 +253,10 @@ class PQLVLearner:
         self.normalize_tuple = None
         self.sleep_time = 0
         self.use_graph = bool(_cfg_get(algo, "graph", False))
+        # RNG draws inside the hipGraph or in front of it.  In front (default): torch hands a captured generator its seed and
+        # Philox offset through two 1-element fill launches per replay (~9 us of device time per step, more than the draws save
+        # by being captured), and the graph no longer bakes in the randint bound, so it is not re-captured while the ring fills.
+        self._graph_rng = bool(_cfg_get(algo, "graph_rng", False))
         # own HIP stream: the MI355X form of the reference's separate learner process (Ray actor).  V-learner,
         # P-learner and rollout queues then overlap on the GPU; hand-offs are event-fenced in update().
         self.stream = torch.cuda.Stream(self.device) if bool(_cfg_get(algo, "streams", False)) else None
@@ -414,12 +418,15 @@ class PQLVLearner:
                         algo.max_grad_norm, algo.tau, 1.0 / self.world, dev, layout=self.critic.layout,
                         packed=self.pk_critic, packed_target=self.pk_target)
 
-    def _draw_and_step(self, ws, upto_backward=False):
-        B = ws["B"]
+    def _draws(self, ws):
         # RNG consumption order of the reference: one randint(cur_capacity,(B,)) then one
         # N(0,1) draw of shape (B, A) on the learner's device generator.
-        torch.randint(self.memory.cur_capacity, (B,), generator=self.gen, out=ws["idx"])   # straight into the workspace: no copy launch
+        torch.randint(self.memory.cur_capacity, (ws["B"],), generator=self.gen, out=ws["idx"])   # straight into the workspace: no copy launch
         ws["draw"].normal_(generator=self.gen)
+
+    def _draw_and_step(self, ws, upto_backward=False, draw=True):
+        if draw:
+            self._draws(ws)
         self._step_kernels(ws, ws["idx"], ws["draw"], upto_backward)
 
     @torch.no_grad()
@@ -443,10 +450,12 @@ class PQLVLearner:
                     ws["draw"].normal_(generator=self.gen)
                 self._step_kernels(ws, ws["idx"], ws["draw"])
             elif self.use_graph:
-                key = (B, self.memory.cur_capacity, id(self.actor), self.normalize_tuple is None)
+                key = (B, self.memory.cur_capacity if self._graph_rng else 0, id(self.actor), self.normalize_tuple is None)
                 if self._graph is None or self._graph_key != key:
                     with H.CAPTURE_LOCK:
                         self._capture(ws, key)
+                if not self._graph_rng:
+                    self._draws(ws)
                 self._graph.replay()
                 if self._graph_post is not None:   # data parallel: the collective stays outside the graphs
                     self._allreduce_grads(ws)
@@ -463,8 +472,8 @@ class PQLVLearner:
         H.release(lease, st)
 
     def _capture(self, ws, key):
-        """Capture the whole step (RNG draws included) into a hipGraph.  The graph bakes in
-        cur_capacity (the randint bound), so it is re-captured while the ring is still filling."""
+        """Capture the whole step into a hipGraph.  With `algo.graph_rng` the RNG draws are captured too; the graph then bakes
+        in cur_capacity (the randint bound) and is re-captured while the ring is still filling."""
         # warm-up outside capture (lazy hipFuncSetAttribute / allocator state), on a side stream as torch requires
         snap = self._snapshot()
         s = torch.cuda.Stream(self.device)
@@ -478,10 +487,10 @@ class PQLVLearner:
         # ONE graph instead of splitting the step around an eager collective
         if not self.dp or graph_collective_enabled(self.pg):
             with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
-                self._draw_and_step(ws)
+                self._draw_and_step(ws, draw=self._graph_rng)
         else:   # two graphs around the RCCL all-reduce (kept eager: no collective is ever captured)
             with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
-                self._draw_and_step(ws, upto_backward=True)
+                self._draw_and_step(ws, upto_backward=True, draw=self._graph_rng)
             g_post = self._new_graph()
             with torch.cuda.graph(g_post, stream=self._capture_stream, capture_error_mode="thread_local"):
                 self._step_post(ws)
@@ -490,7 +499,7 @@ class PQLVLearner:
 
     def _new_graph(self):
         g = torch.cuda.CUDAGraph()
-        if self.gen is not None:    # a private generator takes part in capture only when registered with the graph
+        if self.gen is not None and self._graph_rng:    # a private generator takes part in capture only when registered with the graph
             g.register_generator_state(self.gen)
         return g
 

@@ -83,6 +83,10 @@ def test_streams_and_graphs_are_bit_identical_to_the_serial_schedule(distl):
     for k, a in serial.items():
         if k != "counts":
             assert torch.equal(a, fast[k]), k
+    captured_rng = _run_schedule(48, distl=distl, graph_rng=True)   # the RNG draws inside the graphs instead of in front of them
+    for k, a in serial.items():
+        if k != "counts":
+            assert torch.equal(a, captured_rng[k]), k
     # and the hand-offs did move: the rollout replica holds a policy that has been stepped
     assert not torch.equal(fast["rollout_policy"], _run_schedule(0)["rollout_policy"])
 
