@@ -756,6 +756,8 @@ static int launch_tile(const GemmP& p, int gz, hipStream_t st) {
   const long long big = (long long)((p.M + 127) / 128) * ((ncols + 127) / 128) * gz;
 #if !defined(PQLK_FORCE_TILE64)   // tuning switch: everything on 64x64 tiles (more, smaller, better-interleaving blocks)
   // (128 x 64 tiles at three blocks per CU for the dense products: dX the same, dW 1-2 % slower -- measured, not used)
+  // (the same tiles for launches of exactly one 128 x 128 tile per CU, so that no block sits alone on its CU: neutral to -1 % with
+  //  the LDS-DMA loop -- a lone block there already keeps three tiles in flight)
   if (big >= 256 && ncols >= 128 && EPI != EPI_DTANH_SLICE) return launch_gemm<MODE, 128, 128, EPI>(p, gz, st);
 #endif
   return launch_gemm<MODE, 64, 64, EPI>(p, gz, st);
