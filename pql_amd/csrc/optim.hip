@@ -79,6 +79,20 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
                                                PackSpec ps, LossFold lf) {
   __shared__ float sh[256];
   __shared__ float s_coef, s_step_size, s_bc2_sqrt;
+  // The operands of this thread's first quad are requested BEFORE the norm / step-size preamble (a strided partial load, an
+  // 8-level LDS tree and two double-precision pow() on one thread: a few microseconds during which a block otherwise has
+  // nothing in flight, and most blocks only ever process one quad per thread).
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  auto al16 = [](const void* q) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0; };
+  const bool vec = al16(p) && al16(g) && al16(m) && al16(v) && (!target || al16(target));
+  const int64_t n4 = vec ? (n >> 2) : 0;
+  const int64_t q0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  f4 g4n = f4{0.f, 0.f, 0.f, 0.f}, p4n = g4n, m4n = g4n, v4n = g4n, t4n = g4n;
+  if (q0 < n4) {
+    g4n = reinterpret_cast<const f4*>(g)[q0];
+    p4n = reinterpret_cast<f4*>(p)[q0]; m4n = reinterpret_cast<f4*>(m)[q0]; v4n = reinterpret_cast<f4*>(v)[q0];
+    if (target) t4n = reinterpret_cast<f4*>(target)[q0];
+  }
   if (lf.part && blockIdx.x == 0) {   // block-uniform
     float ls = 0.f;
     for (int i = threadIdx.x; i < lf.n; i += 256) ls += lf.part[i];
@@ -125,18 +139,19 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
     pi = pi + (-step_size) * (mi / denom);       // p.addcdiv_(m, denom, -lr/bc1)
     ti = target ? pi * c.tau + ti * c.one_m_tau : 0.f;   // soft_update
   };
-  typedef float f4 __attribute__((ext_vector_type(4)));
-  auto al16 = [](const void* q) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0; };
-  const bool vec = al16(p) && al16(g) && al16(m) && al16(v) && (!target || al16(target));
-  const int64_t n4 = vec ? (n >> 2) : 0;
   // 16-B path: four consecutive parameters per thread.  Arena blocks start on multiples of 32 floats and rows are
   // multiples of 32 long, so an aligned quad never straddles a packed block and maps to ONE 16-B quad of the
   // fragment-ordered copy (j = k & 3 runs over the quad): the re-pack is a 16-B store too.
-  for (int64_t q4 = (int64_t)blockIdx.x * 256 + threadIdx.x; q4 < n4; q4 += (int64_t)gridDim.x * 256) {
+  for (int64_t q4 = q0; q4 < n4; q4 += (int64_t)gridDim.x * 256) {
     const int64_t i = q4 << 2;
-    const f4 g4 = reinterpret_cast<const f4*>(g)[q4];
-    f4 p4 = reinterpret_cast<f4*>(p)[q4], m4 = reinterpret_cast<f4*>(m)[q4], v4 = reinterpret_cast<f4*>(v)[q4];
-    f4 t4 = target ? reinterpret_cast<f4*>(target)[q4] : f4{0.f, 0.f, 0.f, 0.f};
+    const f4 g4 = g4n;
+    f4 p4 = p4n, m4 = m4n, v4 = v4n, t4 = t4n;
+    const int64_t qn = q4 + (int64_t)gridDim.x * 256;   // the next quad of this thread, requested before this one is stored
+    if (qn < n4) {
+      g4n = reinterpret_cast<const f4*>(g)[qn];
+      p4n = reinterpret_cast<f4*>(p)[qn]; m4n = reinterpret_cast<f4*>(m)[qn]; v4n = reinterpret_cast<f4*>(v)[qn];
+      if (target) t4n = reinterpret_cast<f4*>(target)[qn];
+    }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       float pi = p4[u], mi = m4[u], vi = v4[u], ti = t4[u];
