@@ -53,6 +53,12 @@ def parse():
     ap.add_argument("--nstep", type=int, default=3)
     ap.add_argument("--hidden", default="512,512,256", help="BASELINE shape; the reference default is 512,256,128")
     ap.add_argument("--distl", action="store_true")
+    ap.add_argument("--burn-in-ms", type=float, default=120.0,
+                    help="set-up: keep the matrix pipes busy this long (the V step's MFMA launches on scratch buffers; no learner "
+                         "state is touched) right before the warm-up steps.  After ANY idle gap of >= 10 ms the MFMA kernels of this "
+                         "GPU run ~14 %% slow and recover over the next ~30 ms of load (tools/debug/ramp_after_idle.py), and set-up "
+                         "ends in such gaps: without this a 20-step timed region sits on that ramp.  Recorded in config.burn_in_ms; "
+                         "0 disables")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph-rng", action="store_true", help="capture the learners' RNG draws inside their hipGraphs (A/B; default: in front)")
     ap.add_argument("--no-streams", action="store_true", help="serialise V / P / rollout on one stream")
@@ -137,6 +143,17 @@ def prefill(actor, v, p, env, cfg, args, device):
                 torch.randn((m, O), device=ldev, generator=g), (torch.rand((m, 1), device=ldev, generator=g) < 1 / 300).float())
         critic, _, _ = v.update(pol, traj, actor.obs_rms.get_states(v.device), 0)
         pol, _, _ = p.update(critic, obs, actor.obs_rms.get_states(p.device), 0)
+    # set-up, like the ring fill: a few rollout iterations at the schedule's own horizon with their hand-offs, so that the
+    # trajectory slabs, the three round-robin output blocks, the statistics buffers and the allocator's cache exist before the
+    # first warm-up step (each first-time allocation is a device-synchronising hipMalloc; measured: without this the first
+    # ~40 schedule steps run 5-15 % slow), and the learners' workspaces and hipGraphs (capture restores everything it touches)
+    for _ in range(4):
+        actor.set_actor(pol)
+        p_data, v_data, _ = actor.explore_env(env, cfg.algo.horizon_len, random=False)
+        critic, _, _ = v.update(pol, v_data, actor.obs_rms.get_states(v.device), 0)
+        pol, _, _ = p.update(critic, p_data, actor.obs_rms.get_states(p.device), 0)
+    v.prepare()
+    p.prepare()
     sync_all(device, ldev)
     return critic, pol
 
@@ -475,6 +492,11 @@ def main():
             dt = float(tt.item())
         return dt
 
+    if args.burn_in_ms > 0:
+        t_burn = time.perf_counter()
+        while (time.perf_counter() - t_burn) * 1e3 < args.burn_in_ms:
+            gemm_section_ms(v, iters=8)   # scratch workspaces only: parameters, Adam state and rings untouched
+        note(f"burn-in {args.burn_in_ms:.0f} ms done")
     for _ in range(args.warmup):
         sched.step()
     sync_all(*devices)
@@ -511,7 +533,7 @@ def main():
                                f"{args.replay} rows resident in HBM, batch {args.batch}, n-step {args.nstep}, "
                                f"{'DistributionalDoubleQ(51)' if args.distl else 'DoubleQ'} MLP {hidden}",
                    "schedule": {"schedule": "1 env-iteration : 4 P-steps : 8 V-steps", "v_only": "v_only", "p_only": "p_only"}[mode],
-                   "graph": not args.no_graph, "streams": not args.no_streams, "fused_forward": not args.no_fused,
+                   "graph": not args.no_graph, "burn_in_ms": args.burn_in_ms, "streams": not args.no_streams, "fused_forward": not args.no_fused,
                    "parallelism": par, "layout": args.layout if args.gpus > 1 else "single", "ranks": world,
                    "backend": backend, "share_gpu": bool(args.share_gpu)},
         "repeats": {"blocks": len(blocks), "steps_per_block": args.steps, "median": rates[len(rates) // 2], "min": rates[0],

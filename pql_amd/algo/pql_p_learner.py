@@ -240,6 +240,19 @@ class PQLPLearner:
         self.update_count += 1
         return self.sleep_time
 
+    @torch.no_grad()
+    def prepare(self):
+        """Workspace + hipGraph capture now instead of inside the first `learn()` (side-effect free, see PQLVLearner.prepare)."""
+        if self.critic is None:
+            return
+        with self._lock, torch.cuda.device(self.device), self._on_stream():
+            ws = self._workspace(int(self.cfg.algo.batch_size))
+            if self.use_graph:
+                key = (ws["B"], self.cur_capacity if self._graph_rng else 0, id(self.critic), self.normalize_tuple is None)
+                if self._graph is None or self._graph_key != key:
+                    with H.CAPTURE_LOCK:
+                        self._capture(ws, key)
+
     def _state(self):
         return (self.actor.arena.data, self.opt.m, self.opt.v, self.opt.step, self.loss_ring)
 

@@ -465,6 +465,20 @@ class PQLVLearner:
         self.update_count += 1
         return self.sleep_time
 
+    @torch.no_grad()
+    def prepare(self):
+        """Build the workspace and capture the step's hipGraph now instead of inside the first `learn()` (capture runs one
+        step and restores every tensor and the RNG state it touched, so this changes nothing observable)."""
+        if self.actor is None:
+            return
+        with self._lock, torch.cuda.device(self.device), self._on_stream():
+            ws = self._workspace(int(self.cfg.algo.batch_size))
+            if self.use_graph:
+                key = (ws["B"], self.memory.cur_capacity if self._graph_rng else 0, id(self.actor), self.normalize_tuple is None)
+                if self._graph is None or self._graph_key != key:
+                    with H.CAPTURE_LOCK:
+                        self._capture(ws, key)
+
     def _inject(self, dst, src, home):
         st = torch.cuda.current_stream(self.device)
         lease = H.acquire(src, st, home) if src.is_cuda else None
