@@ -121,7 +121,7 @@ def build_system(args, rank, world, device, pg, learner_device=None):
     return cfg, env, actor, v, p
 
 
-def prefill(actor, v, p, env, cfg, args, device):
+def prefill(actor, v, p, env, cfg, args, device, prepare=("v", "p")):
     """Warm-up rollout (train_pql.py:57-68), then fill both replay rings to capacity with synthetic rows so the
     randint bound is constant and samples come from HBM, not cache.  Returns the newest (critic, policy) snapshots."""
     critic, _, _ = v.start()
@@ -152,8 +152,10 @@ def prefill(actor, v, p, env, cfg, args, device):
         p_data, v_data, _ = actor.explore_env(env, cfg.algo.horizon_len, random=False)
         critic, _, _ = v.update(pol, v_data, actor.obs_rms.get_states(v.device), 0)
         pol, _, _ = p.update(critic, p_data, actor.obs_rms.get_states(p.device), 0)
-    v.prepare()
-    p.prepare()
+    if "v" in prepare:
+        v.prepare()
+    if "p" in prepare:   # (a --v-only profile run never steps the P-learner, not even inside its graph capture)
+        p.prepare()
     sync_all(device, ldev)
     return critic, pol
 
@@ -466,9 +468,9 @@ def main():
     t_start = time.perf_counter()
     cfg, env, actor, v, p = build_system(args, rank, world, device, pg, learner_device)
     note("system built")
-    critic, policy = prefill(actor, v, p, env, cfg, args, device)
-    note(f"replay pre-filled: {v.memory.cur_capacity} rows x {v.memory.ring.rec_ld * 4} B")
     mode = "v_only" if args.v_only else "p_only" if args.p_only else "schedule"
+    critic, policy = prefill(actor, v, p, env, cfg, args, device, prepare={"v_only": ("v",), "p_only": ("p",)}.get(mode, ("v", "p")))
+    note(f"replay pre-filled: {v.memory.cur_capacity} rows x {v.memory.ring.rec_ld * 4} B")
     sched = Schedule(actor, v, p, env, cfg, device, critic, policy, mode=mode)
     devices = (device, v.device, p.device)
 
