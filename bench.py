@@ -237,7 +237,7 @@ def gemm_section_ms(v, iters=20):
             section()
         torch.cuda.current_stream(v.device).wait_stream(side)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # (a process-group watchdog thread may poll events meanwhile)
             for _ in range(iters):
                 section()
         g.replay()
@@ -270,7 +270,7 @@ def dominant_kernel_ms(v, iters=20):
         with torch.cuda.stream(side):
             one()
         torch.cuda.current_stream(v.device).wait_stream(side)
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # (a process-group watchdog thread may poll events meanwhile)
             for _ in range(iters):
                 one()
         g.replay()
@@ -308,7 +308,7 @@ def gather_ms(v, iters=50):
         with torch.cuda.stream(side):
             one(0)
         torch.cuda.current_stream(v.device).wait_stream(side)
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):   # (a process-group watchdog thread may poll events meanwhile)
             for i in range(iters):
                 one(3 + i)
         g.replay()
