@@ -1,0 +1,52 @@
+"""The committed measurement artefacts stay self-consistent: the newest bench line carries every key of the bench contract, its
+roofline numbers follow from its own inputs, and the reducers under tools/ still read the committed rocprofv3 files."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _newest(pattern):
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    assert paths, pattern
+    return paths[-1]
+
+
+def test_newest_bench_line_honours_the_contract():
+    d = json.load(open(_newest("r*_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["steps"] / (d["ms_per_step"] * d["steps"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - d["gflop_per_v_step"] / r["ms_per_launch_group"]) < 1e-6 * r["achieved"]   # GFLOP / ms = TFLOP/s
+    assert 0.3 < r["frac"] < 1.0 and r["traffic"] is None or r["traffic"] > 1e8
+    g = d["roofline_gather"]
+    assert g["bound"] == "hbm" and abs(g["frac"] - g["achieved"] / g["peak"]) < 1e-9
+    assert abs(g["achieved"] - g["algorithmic_bytes"] / (g["us_per_launch"] * 1e-6) / 1e9) < 1e-6 * g["achieved"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert d["value"] / c["value"] > 10     # north_star: >= 10x the CPU learner on one MI355X
+
+
+def test_reducers_read_the_committed_rocprof_files():
+    stats = _newest("r*_v_only_kernel_stats.csv")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "roofline_from_stats.py"), stats], capture_output=True, text=True,
+                         timeout=120)
+    assert out.returncode == 0, out.stderr
+    rows = [l for l in out.stdout.splitlines() if l.startswith("| `k_mlp_fwd_fused<2, 2>")]
+    assert rows and 0.5 < float(rows[0].split("|")[-2]) < 0.95
+    traffic = json.load(open(_newest("r*_pmc_traffic.json")))
+    assert 2e8 < traffic["mfma_family_per_v_step_bytes"] < 2e9 and 1e7 < traffic["gather_per_launch_bytes"] < 3e7
+    util = json.load(open(_newest("r*_pmc_mfma.json")))["kernels"]
+    fused = [v for k, v in util.items() if k.startswith("k_mlp_fwd_fused<2, 2>")]
+    assert fused and 0.5 < fused[0]["mfma_util"] < 0.95
+    # the counters' FLOP count of the twin-critic forward = the algorithmic one plus the padding of the 104-wide input to 128
+    assert 14.6 < fused[0]["gflop_per_dispatch_from_counters"] < 15.6
