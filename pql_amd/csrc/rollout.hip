@@ -120,3 +120,74 @@ extern "C" int pqlk_rollout_step(int64_t n, int32_t obs_dim, int32_t act_dim, in
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// The rest of the per-env-step ATen micro-kernels of the rollout, one launch each (were 12 + 4 + 4 launches):
+//   RunningMeanStd.update_from_moments (pql/utils/torch_util.py:91-103), op for op in fp32 with the python scalars rounded to
+//   fp32 where torch rounds them; RunningMeanStd.normalize (:83-85); add_normal_noise / add_mixed_normal_noise (noise.py:19-41).
+__global__ __launch_bounds__(256) void k_rms_merge(const float* __restrict__ mean, const float* __restrict__ var,
+                                                   const float* __restrict__ bm, const float* __restrict__ bv, float count, float bcount,
+                                                   float tot, int cols, float* __restrict__ mean_out, float* __restrict__ var_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= cols) return;
+  const float delta = bm[i] - mean[i];
+  const float m2 = (var[i] * count + bv[i] * bcount) + (((delta * delta) * count) * bcount) / tot;
+  mean_out[i] = mean[i] + (delta * bcount) / tot;
+  var_out[i] = m2 / tot;
+}
+
+extern "C" int pqlk_rms_merge(const float* mean, const float* var, const float* batch_mean, const float* batch_var, float count,
+                              float batch_count, float total, int32_t cols, float* mean_out, float* var_out, pqlk_stream_t stream) {
+  PQLK_REQUIRE(mean && var && batch_mean && batch_var && mean_out && var_out, PQLK_E_NULL);
+  PQLK_REQUIRE(cols > 0 && total > 0.f, PQLK_E_SHAPE);
+  hipLaunchKernelGGL(k_rms_merge, dim3((unsigned)((cols + 255) / 256)), dim3(256), 0, pqlk_s(stream), mean, var, batch_mean, batch_var,
+                     count, batch_count, total, cols, mean_out, var_out);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}
+
+__global__ __launch_bounds__(256) void k_rms_normalize(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ var, float eps, long long total, int cols,
+                                                       float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % cols);
+    out[i] = (x[i] - mean[c]) / sqrtf(var[c] + eps);
+  }
+}
+
+extern "C" int pqlk_rms_normalize(const float* x, int64_t rows, int32_t cols, const float* mean, const float* var, float eps, float* out,
+                                  pqlk_stream_t stream) {
+  PQLK_REQUIRE(x && mean && var && out, PQLK_E_NULL);
+  PQLK_REQUIRE(rows > 0 && cols > 0, PQLK_E_SHAPE);
+  const long long total = rows * (long long)cols;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_rms_normalize, dim3((unsigned)blocks), dim3(256), 0, pqlk_s(stream), x, mean, var, eps, total, cols, out);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}
+
+// out = clamp(act + draw * sigma, lo, hi); sigma = std_rows[row] (mixed noise: one sigma per env) or std_scalar
+__global__ __launch_bounds__(256) void k_action_noise(const float* __restrict__ act, const float* __restrict__ draw,
+                                                      const float* __restrict__ std_rows, float std_scalar, long long total, int cols,
+                                                      float lo, float hi, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const float sigma = std_rows ? std_rows[i / cols] : std_scalar;
+    const float noise = draw[i] * sigma;
+    out[i] = fminf(fmaxf(act[i] + noise, lo), hi);
+  }
+}
+
+extern "C" int pqlk_action_noise(const float* act, const float* draw, const float* std_rows, float std_scalar, int64_t rows, int32_t cols,
+                                 float lo, float hi, float* out, pqlk_stream_t stream) {
+  PQLK_REQUIRE(act && draw && out, PQLK_E_NULL);
+  PQLK_REQUIRE(rows > 0 && cols > 0 && lo <= hi, PQLK_E_SHAPE);
+  const long long total = rows * (long long)cols;
+  long long blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_action_noise, dim3((unsigned)blocks), dim3(256), 0, pqlk_s(stream), act, draw, std_rows, std_scalar, total, cols, lo,
+                     hi, out);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}

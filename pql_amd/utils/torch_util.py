@@ -69,15 +69,34 @@ class RunningMeanStd:
             self.update_from_moments(gathered[r, 0].view(self.mean.shape), gathered[r, 1].view(self.mean.shape), n)
 
     def update_from_moments(self, batch_mean, batch_var, batch_count):
-        delta = batch_mean - self.mean
         tot = self.count + batch_count
+        if (self.mean.is_cuda and self.mean.dtype == torch.float32 and batch_mean.is_cuda and batch_mean.dtype == torch.float32
+                and batch_var.dtype == torch.float32 and self.mean.is_contiguous() and self.var.is_contiguous()):
+            # one launch instead of twelve; new tensors, like the torch expression below: what get_states() handed out stays a snapshot
+            bm, bv = batch_mean.contiguous(), batch_var.contiguous()
+            mean, var = torch.empty_like(self.mean), torch.empty_like(self.var)
+            with torch.cuda.device(self.mean.device):
+                L.check(L.lib.pqlk_rms_merge(L.ptr(self.mean), L.ptr(self.var), L.ptr(bm), L.ptr(bv), float(self.count),
+                                             float(batch_count), float(tot), self.mean.numel(), L.ptr(mean), L.ptr(var),
+                                             L.stream(self.mean.device)))
+            self.mean, self.var, self.count = mean, var, tot
+            return
+        delta = batch_mean - self.mean
         m2 = self.var * self.count + batch_var * batch_count + delta ** 2 * self.count * batch_count / tot
         self.mean = self.mean + delta * batch_count / tot
         self.var = m2 / tot
         self.count = tot
 
     def normalize(self, x):
-        return (x - self.mean) / torch.sqrt(self.var + self.epsilon)  # actor side: no clamp (torch_util.py:83-85)
+        """Actor side: no clamp (torch_util.py:83-85)."""
+        if (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and self.mean.is_cuda and x.dim() >= 1
+                and x.shape[-1] == self.mean.numel() and self.mean.dim() == 1 and x.numel() > 0):
+            out = torch.empty_like(x)
+            with torch.cuda.device(x.device):
+                L.check(L.lib.pqlk_rms_normalize(L.ptr(x), x.numel() // x.shape[-1], x.shape[-1], L.ptr(self.mean), L.ptr(self.var),
+                                                 float(self.epsilon), L.ptr(out), L.stream(x.device)))
+            return out
+        return (x - self.mean) / torch.sqrt(self.var + self.epsilon)
 
     def unnormalize(self, x):
         return x * torch.sqrt(self.var + self.epsilon) + self.mean

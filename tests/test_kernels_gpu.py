@@ -869,3 +869,41 @@ def test_gemm_lds_dma_loop_is_bitwise_the_register_staged_loop(dev):
         hashes[name] = r.stdout.strip().split()
     assert len(hashes["dma+xcd"]) == 3
     assert hashes["dma+xcd"] == hashes["staged"] == hashes["dma, dispatch order"], hashes
+
+
+# --------------------------------------------------------------------------- the rollout's elementwise launches
+def test_rms_merge_normalize_and_action_noise_kernels_match_the_cpu_expressions(dev):
+    """pqlk_rms_merge / pqlk_rms_normalize / pqlk_action_noise against the reference's torch expressions evaluated on the CPU
+    (pql/utils/torch_util.py:83-103, noise.py:19-41): bit for bit -- same fp32 operations in the same order, IEEE division."""
+    from pql_amd.utils.noise import add_mixed_normal_noise, add_normal_noise
+    from pql_amd.utils.torch_util import RunningMeanStd
+    O, N, A = 88, 4096, 16
+    rms = RunningMeanStd(shape=(O,), device=dev)
+    mean_c, var_c, count = torch.zeros(O), torch.ones(O), 1e-4
+    for step in range(5):
+        bm, bv = T(dd.uniform((O,), 600 + step, -1, 1)), T(dd.uniform((O,), 610 + step, 0.1, 3.0))
+        n = 4096 if step else 131072      # warm-up batch of 32 steps, then one step
+        rms.update_from_moments(bm.to(dev), bv.to(dev), n)
+        delta = bm - mean_c               # the reference expression on the CPU
+        tot = count + n
+        m2 = var_c * count + bv * n + delta ** 2 * count * n / tot
+        mean_c = mean_c + delta * n / tot
+        var_c = m2 / tot
+        count = tot
+        assert torch.equal(rms.mean.cpu(), mean_c) and torch.equal(rms.var.cpu(), var_c) and rms.count == count
+    x = T(dd.uniform((N, O), 620, -4, 4))
+    # (sqrt through numpy: torch's vectorised CPU sqrt is 1 ulp off on ~0.6 % of inputs on some hosts, DESIGN section 2)
+    want = (x - mean_c) / torch.from_numpy(np.sqrt((var_c + 1e-4).numpy()))
+    assert torch.equal(rms.normalize(x.to(dev)).cpu(), want)
+    act, draw = T(dd.uniform((N, A), 630, -1, 1)), T(dd.uniform((N, A), 631, -3, 3))
+    std = torch.linspace(0.05, 0.8, N).unsqueeze(-1)
+    got = add_mixed_normal_noise(act.to(dev), std_max=0.8, std_min=0.05, out_bounds=[-1., 1.], draw=draw.to(dev))
+    assert torch.equal(got.cpu(), (act + draw * std).clamp(-1., 1.))
+    got = add_normal_noise(act.to(dev), std=0.3, out_bounds=[-1., 1.], draw=draw.to(dev))
+    assert torch.equal(got.cpu(), (act + draw * 0.3).clamp(-1., 1.))
+    # un-injected: the generator is consumed exactly like torch.normal(zeros, std) consumes it
+    g1, g2 = torch.Generator(device=dev), torch.Generator(device=dev)
+    g1.manual_seed(5); g2.manual_seed(5)
+    a = add_mixed_normal_noise(act.to(dev), std_max=0.8, std_min=0.05, out_bounds=[-1., 1.], generator=g1)
+    b = (act.to(dev) + torch.empty((N, A), device=dev).normal_(generator=g2) * std.to(dev)).clamp(-1., 1.)
+    assert torch.equal(a, b)
