@@ -394,13 +394,13 @@ int pqlk_rollout_step(int64_t n, int32_t obs_dim, int32_t act_dim, int32_t horiz
 /* The remaining per-env-step elementwise work of the rollout, one launch each (the reference issues 12 + 4 + 4 ATen launches):
  * RunningMeanStd.update_from_moments (pql/utils/torch_util.py:91-103): Chan merge of one batch's moments into the running
  * ones, op for op in fp32 (count / batch_count / total = the python scalars rounded to fp32 as torch rounds them), written to
- * mean_out / var_out (may alias mean / var); RunningMeanStd.normalize (:83-85): (x - mean) / sqrt(var + eps) over a contiguous
- * (rows, cols) matrix, IEEE division, no clamp; add_normal_noise / add_mixed_normal_noise (pql/utils/noise.py:19-41):
+ * mean_out / var_out (may alias mean / var); RunningMeanStd.normalize (:83-85): (x - mean) / sqrt(var + eps) of a contiguous
+ * (rows, cols) matrix into rows of stride ld_out (columns past cols untouched), IEEE division, no clamp; add_normal_noise / add_mixed_normal_noise (pql/utils/noise.py:19-41):
  * out = clamp(act + draw * sigma, lo, hi) with sigma = std_rows[row] (one per env) when std_rows != NULL, else std_scalar. */
 int pqlk_rms_merge(const float* mean, const float* var, const float* batch_mean, const float* batch_var, float count,
                    float batch_count, float total, int32_t cols, float* mean_out, float* var_out, pqlk_stream_t stream);
 int pqlk_rms_normalize(const float* x, int64_t rows, int32_t cols, const float* mean, const float* var, float eps, float* out,
-                       pqlk_stream_t stream);
+                       int64_t ld_out, pqlk_stream_t stream);
 int pqlk_action_noise(const float* act, const float* draw, const float* std_rows, float std_scalar, int64_t rows, int32_t cols,
                       float lo, float hi, float* out, pqlk_stream_t stream);
 

@@ -78,7 +78,7 @@ PROTOTYPES = {
     "pqlk_rollout_step": (C.c_int, [_I64, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _P]),
     "pqlk_batch_moments": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P, _P]),
     "pqlk_rms_merge": (C.c_int, [_P, _P, _P, _P, _F, _F, _F, _I32, _P, _P, _P]),
-    "pqlk_rms_normalize": (C.c_int, [_P, _I64, _I32, _P, _P, _F, _P, _P]),
+    "pqlk_rms_normalize": (C.c_int, [_P, _I64, _I32, _P, _P, _F, _P, _I64, _P]),
     "pqlk_action_noise": (C.c_int, [_P, _P, _P, _F, _I64, _I32, _F, _F, _P, _P]),
 }
 

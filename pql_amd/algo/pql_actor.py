@@ -53,7 +53,7 @@ class PQLActor:
         self.v_learner_device = torch.device(f"cuda:{cfg.algo.v_learner_gpu}")
         self.p_learner_device = torch.device(f"cuda:{cfg.algo.p_learner_gpu}")
         self.env_offset, self.total_envs = int(env_offset), total_envs   # position on the GLOBAL env axis (data parallel)
-        self.actor = None   # rollout replica of the policy, assigned by the driver
+        self._actor = None  # rollout replica of the policy, assigned by the driver (`actor` is a property: see below)
         self.obs = None
         if cfg.info_track_keys is not None:
             raise NotImplementedError("info_track_keys needs a simulator's info dict; out of scope")
@@ -72,6 +72,9 @@ class PQLActor:
         if self.sim_device.type == "cuda":
             self.gen = torch.Generator(device=self.sim_device)
             self.gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
+        self._pk = None        # fragment-ordered copy of the rollout replica's weights (fused policy forward), see set_actor
+        self._pk_stale = True  # re-derived at the start of every explore_env and after set_actor / assignment of `.actor`
+        self._fwd_buf = None   # (zero-padded input tile, activation scratch) of the fused policy forward
         self._slabs = {}   # (N, T, .) trajectory slabs, allocated once per horizon length and reused
         # n-step output blocks handed to the learners: OUT_BLOCKS per block size, each with a lease so that the rollout
         # stream re-uses one only after the learners' streams have inserted it (pql_amd.utils.handoff)
@@ -101,8 +104,7 @@ class PQLActor:
     def get_actions(self, obs, sample=True, draw=None):
         """Policy action on rollout-normalised observations (no +-5 clamp on this side, torch_util.py:83-85), plus
         exploration noise: 'mixed' = per-env sigma spread over [std_min, std_max] along the global env axis."""
-        x = self.obs_rms.normalize(obs) if self.cfg.algo.obs_norm else obs
-        act = self.actor(x)
+        act = self._policy_forward(obs)
         if not sample:
             return act
         noise = self.cfg.algo.noise
@@ -113,6 +115,55 @@ class PQLActor:
             return add_normal_noise(act, std=self.get_noise_std(), out_bounds=[-1., 1.], generator=self.gen, draw=draw)
         raise NotImplementedError(noise.type)
 
+    @property
+    def actor(self):
+        return self._actor
+
+    @actor.setter
+    def actor(self, module):   # the reference idiom `pql_actor.actor = deepcopy(actor).to(sim_device)` (train_pql.py:52,109)
+        self._actor = module
+        self._pk_stale = True
+
+    def _policy_forward(self, obs):
+        """tanh(MLP(normalise(obs))) of the rollout replica.  TanhMLPPolicy on the GPU: the observation is normalised straight
+        into the policy's zero-padded input tile and the whole network is ONE fused launch writing a contiguous (N, A) action
+        matrix (`pqlk_mlp_forward` with the fragment-ordered weight copy refreshed in set_actor); anything else goes through
+        the module's own forward."""
+        from pql_amd import _lib as L
+        from pql_amd.models.mlp import mlp_forward_raw
+        if self._pk_stale:
+            self._refresh_packed()
+        pk = self._pk
+        if (pk is None or pk.tensor is None or getattr(self.actor, "out_act", None) != L.ACT_TANH or not obs.is_cuda
+                or obs.dtype != torch.float32 or not obs.is_contiguous() or obs.dim() != 2):
+            return self.actor(self.obs_rms.normalize(obs) if self.cfg.algo.obs_norm else obs)
+        lay, n = self.actor.layout, obs.shape[0]
+        buf = self._fwd_buf
+        if buf is None or buf[0].shape[0] != n:
+            dev = obs.device
+            buf = self._fwd_buf = (torch.zeros((n, lay.ld_in), dtype=torch.float32, device=dev),
+                                   torch.empty(lay.acts_floats(n), dtype=torch.float32, device=dev))
+        x_pad, acts = buf
+        if self.cfg.algo.obs_norm:
+            self.obs_rms.normalize(obs, out=x_pad)
+        else:
+            x_pad[:, : obs.shape[1]].copy_(obs)
+        act = torch.empty((n, self.action_dim), dtype=torch.float32, device=obs.device)
+        mlp_forward_raw(lay, self.actor.arena.data, x_pad, L.ACT_TANH, acts=acts, out2=act, packed=pk, stash_all=False)
+        return act
+
+    def _refresh_packed(self):
+        from pql_amd.models.mlp import PackedWeights
+        if self.sim_device.type != "cuda" or not hasattr(self.actor, "layout"):
+            self._pk, self._pk_stale = None, False
+            return
+        if self._pk is None or self._pk.layout.dims != self.actor.layout.dims:
+            self._pk = PackedWeights(self.actor.layout, self.sim_device)
+            self._fwd_buf = None
+        with torch.cuda.device(self.sim_device):
+            self._pk.refresh(self.actor.arena.data)
+        self._pk_stale = False
+
     @torch.no_grad()
     def set_actor(self, actor):
         """Adopt new policy weights into the rollout replica (train_pql.py:52,109 `pql_actor.actor = deepcopy(actor).to(
@@ -122,6 +173,7 @@ class PQLActor:
             self.actor = deepcopy(actor).to(self.sim_device)
             return
         if actor is self.actor:
+            self._pk_stale = True   # the caller may have stepped or loaded it in place
             return
         st = torch.cuda.current_stream(self.sim_device)
         with H.LOCK:
@@ -133,6 +185,7 @@ class PQLActor:
                 lease = H.acquire(actor, st)
                 self.actor.arena.data.copy_(actor.arena.data, non_blocking=True)
             H.release(lease, st)
+        self._pk_stale = True
 
     def _out_block(self, M):
         """Next n-step output block of M rows (round robin), reclaimed from its previous readers."""
@@ -169,6 +222,7 @@ class PQLActor:
         `random`, N(0,1) otherwise -- the two draws the reference makes (pql_actor.py:101, noise.py:34-35)."""
         algo, n = self.cfg.algo, self.cfg.num_envs
         sl = self._trajectory_slabs(timesteps)
+        self._pk_stale = True   # the replica may have been stepped or loaded in place since the last call: re-pack once per call
         obs = self.obs
         for t in range(timesteps):
             if self.obs_rms is not None:

@@ -149,21 +149,23 @@ extern "C" int pqlk_rms_merge(const float* mean, const float* var, const float* 
 
 __global__ __launch_bounds__(256) void k_rms_normalize(const float* __restrict__ x, const float* __restrict__ mean,
                                                        const float* __restrict__ var, float eps, long long total, int cols,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, long long ld_out) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const int c = (int)(i % cols);
-    out[i] = (x[i] - mean[c]) / sqrtf(var[c] + eps);
+    const long long row = i / cols;
+    const int c = (int)(i - row * cols);
+    out[row * ld_out + c] = (x[i] - mean[c]) / sqrtf(var[c] + eps);
   }
 }
 
 extern "C" int pqlk_rms_normalize(const float* x, int64_t rows, int32_t cols, const float* mean, const float* var, float eps, float* out,
-                                  pqlk_stream_t stream) {
+                                  int64_t ld_out, pqlk_stream_t stream) {
   PQLK_REQUIRE(x && mean && var && out, PQLK_E_NULL);
-  PQLK_REQUIRE(rows > 0 && cols > 0, PQLK_E_SHAPE);
+  PQLK_REQUIRE(rows > 0 && cols > 0 && ld_out >= cols, PQLK_E_SHAPE);
   const long long total = rows * (long long)cols;
   long long blocks = (total + 255) / 256;
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_rms_normalize, dim3((unsigned)blocks), dim3(256), 0, pqlk_s(stream), x, mean, var, eps, total, cols, out);
+  hipLaunchKernelGGL(k_rms_normalize, dim3((unsigned)blocks), dim3(256), 0, pqlk_s(stream), x, mean, var, eps, total, cols, out,
+                     (long long)ld_out);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }

@@ -87,15 +87,19 @@ class RunningMeanStd:
         self.var = m2 / tot
         self.count = tot
 
-    def normalize(self, x):
-        """Actor side: no clamp (torch_util.py:83-85)."""
+    def normalize(self, x, out=None):
+        """Actor side: no clamp (torch_util.py:83-85).  `out`: optional (rows, >= cols) fp32 matrix to write into (row stride
+        `out.stride(0)`, columns past `cols` untouched) -- the policy's zero-padded input tile."""
         if (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and self.mean.is_cuda and x.dim() >= 1
                 and x.shape[-1] == self.mean.numel() and self.mean.dim() == 1 and x.numel() > 0):
-            out = torch.empty_like(x)
+            dst = torch.empty_like(x) if out is None else out
             with torch.cuda.device(x.device):
                 L.check(L.lib.pqlk_rms_normalize(L.ptr(x), x.numel() // x.shape[-1], x.shape[-1], L.ptr(self.mean), L.ptr(self.var),
-                                                 float(self.epsilon), L.ptr(out), L.stream(x.device)))
-            return out
+                                                 float(self.epsilon), L.ptr(dst), x.shape[-1] if out is None else out.stride(0),
+                                                 L.stream(x.device)))
+            return dst
+        if out is not None:
+            raise L.PqlkError("RunningMeanStd.normalize(out=...) needs contiguous fp32 GPU tensors")
         return (x - self.mean) / torch.sqrt(self.var + self.epsilon)
 
     def unnormalize(self, x):
