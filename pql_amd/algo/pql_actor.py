@@ -154,7 +154,8 @@ class PQLActor:
 
     def _refresh_packed(self):
         from pql_amd.models.mlp import PackedWeights
-        if self.sim_device.type != "cuda" or not hasattr(self.actor, "layout"):
+        fused = self.cfg.algo.get("fused", True) if hasattr(self.cfg.algo, "get") else getattr(self.cfg.algo, "fused", True)
+        if self.sim_device.type != "cuda" or not hasattr(self.actor, "layout") or not fused:   # algo.fused=False: per-layer GEMMs everywhere
             self._pk, self._pk_stale = None, False
             return
         if self._pk is None or self._pk.layout.dims != self.actor.layout.dims:
