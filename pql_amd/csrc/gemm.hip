@@ -357,6 +357,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
         gb[u] = B + (long long)(kbeg + row) * p.ldb + n0 + 4 * c4;
       }
       const long long a_step = (MODE == MODE_DX) ? (long long)KT : (long long)KT * p.lda, b_step = (long long)KT * p.ldb;
+      // (M0 -- the DMA's LDS base -- is written inside the asm.  It is a register reserved to the compiler, which therefore never
+      //  keeps a value of its own in it across foreign code; this kernel has no other M0 user: no LDS-DMA builtin, no
+      //  readlane / movrel / sendmsg.  Naming it as a clobber only draws -Winline-asm's "reserved register" warning.)
       int issued = 0;   // tiles requested so far; past the last one the tail re-requests it into a stage nobody reads again
 #define PQLK_DMA(STG)                                                                                                          \
   do {                                                                                                                         \
