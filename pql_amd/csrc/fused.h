@@ -386,13 +386,19 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
   if (p.head_n > 0) fused_head<R>(p, net, row0, buf_ld4, wave, lane);   // the LDS buffer holds the last hidden layer's output
 }
 
-// arena -> fragment-ordered copy of the hidden layers' weights (one thread per element; 1-3 M elements)
-__global__ __launch_bounds__(256) void k_mlp_pack(const float* __restrict__ params, float* __restrict__ packed, long long w_off,
-                                                  long long p_off, int N, int K, int ldk, long long net_stride,
-                                                  long long packed_net_stride) {
-  const int net = blockIdx.y;
-  const float* W = params + (long long)net * net_stride + w_off;
-  float* dst = packed + (long long)net * packed_net_stride + p_off;
+// arena -> fragment-ordered copy of the hidden layers' weights (one thread per element; 1-3 M elements); ONE launch for all
+// hidden layers: grid.z = layer (a re-pack follows every weight hand-off, three per rollout iteration)
+struct PackP {
+  int n_layers;
+  long long w_off[PQLK_MAX_LAYERS], p_off[PQLK_MAX_LAYERS];
+  int N[PQLK_MAX_LAYERS], K[PQLK_MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void k_mlp_pack(const float* __restrict__ params, float* __restrict__ packed, PackP pp,
+                                                  long long net_stride, long long packed_net_stride) {
+  const int net = blockIdx.y, layer = blockIdx.z;
+  const int N = pp.N[layer], K = pp.K[layer], ldk = K;
+  const float* W = params + (long long)net * net_stride + pp.w_off[layer];
+  float* dst = packed + (long long)net * packed_net_stride + pp.p_off[layer];
   const long long total = (long long)N * K;
   const int K8 = K >> 3;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {

@@ -891,18 +891,23 @@ extern "C" int pqlk_mlp_pack(const PqlMlpDesc* d, const float* params, float* pa
   PQLK_REQUIRE(params && packed, PQLK_E_NULL);
   PQLK_REQUIRE(fusable(d, nullptr), PQLK_E_UNSUPPORTED);
   const int64_t net_stride = pqlk_mlp_net_stride(d), pstride = packed_net_stride(d);
-  int64_t p_off = 0;
+  PackP pp = {};
+  int64_t p_off = 0, most = 0;
   for (int l = 0; l + 1 < d->n_layers; ++l) {
     int64_t w_off, b_off;
     pqlk_mlp_layer_offsets(d, l, &w_off, &b_off);
-    const int N = d->dims[l + 1], K = (int)pqlk_ld(d->dims[l]);
-    int blocks = (int)(((int64_t)N * K + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_mlp_pack, dim3(blocks, d->n_nets), dim3(256), 0, pqlk_s(stream), params, packed, (long long)w_off,
-                       (long long)p_off, N, K, K, (long long)net_stride, (long long)pstride);
-    PQLK_LAUNCH_CHECK();
-    p_off += (int64_t)N * K;
+    pp.w_off[l] = w_off; pp.p_off[l] = p_off;
+    pp.N[l] = d->dims[l + 1]; pp.K[l] = (int)pqlk_ld(d->dims[l]);
+    const int64_t elems = (int64_t)pp.N[l] * pp.K[l];
+    if (elems > most) most = elems;
+    p_off += elems;
   }
+  pp.n_layers = d->n_layers - 1;
+  int blocks = (int)((most + 255) / 256);   // sized for the largest layer; the kernel's loop is grid-strided
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_mlp_pack, dim3(blocks, d->n_nets, pp.n_layers), dim3(256), 0, pqlk_s(stream), params, packed, pp,
+                     (long long)net_stride, (long long)pstride);
+  PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }
 
