@@ -34,6 +34,10 @@ struct FusedP {
   const float* params;  // parameter arena (biases are read from here)
   const float* packed;  // fragment-ordered hidden-layer weights
   float* acts;          // activation stash (layout of pqlk_mlp_act_offset)
+  // pair != 0: a SECOND problem of the same layout and batch rides in the same launch (pqlk_mlp_forward_pair: the target critic
+  // and the critic of a V-learner step): 2 x the blocks, XCDs 0-3 take problem one, 4-7 problem two
+  const float* X2; const float* params2; const float* packed2; float* acts2;
+  int pair, stash_all2;
   int B, ldx, n_hidden, stash_all, buf_ld, n_nets;
   int dims[PQLK_MAX_LAYERS + 1];  // in (logical), h1, h2, ...
   long long net_stride, packed_net_stride;
@@ -219,11 +223,12 @@ __device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, in
 enum { HEAD_NONE = PQLK_ACT_NONE, HEAD_TANH = PQLK_ACT_TANH, HEAD_TANH_NOISE = PQLK_ACT_TANH_NOISE };
 
 template <int R>
-__device__ __forceinline__ void fused_head(const FusedP& p, int net, int row0, int buf_ld4, int wave, int lane) {
+__device__ __forceinline__ void fused_head(const FusedP& p, const float* __restrict__ params, float* __restrict__ acts, int net, int row0,
+                                           int buf_ld4, int wave, int lane) {
   constexpr int NW = FUSED_NW;
   const int r = lane & 31, h = lane >> 5;
   const int Kh = p.dims[p.n_hidden], K8 = Kh >> 3, N = p.head_n;
-  const float* W = p.params + (long long)net * p.net_stride + p.head_w_off;     // (N, Kh) row-major: Kh % 32 == 0 -> ld = Kh
+  const float* W = params + (long long)net * p.net_stride + p.head_w_off;     // (N, Kh) row-major: Kh % 32 == 0 -> ld = Kh
   const float4* wp = reinterpret_cast<const float4*>(W + (long long)min(r, N - 1) * Kh) + h;   // rows past N: clamped, never stored
   const float4* lds4 = reinterpret_cast<const float4*>(fsm);
   const int per = (K8 + NW - 1) / NW, k0 = wave * per, k1 = min(K8, k0 + per);
@@ -249,8 +254,8 @@ __device__ __forceinline__ void fused_head(const FusedP& p, int net, int row0, i
 #pragma unroll
     for (int e = 0; e < 16; ++e) fsm[((wave * R + i) * 16 + e) * 64 + lane] = acc[i][e];
   __syncthreads();
-  const float* bias = p.params + (long long)net * p.net_stride + p.head_b_off;
-  float* out = p.acts + p.head_a_off + (long long)net * p.B * p.head_ld;
+  const float* bias = params + (long long)net * p.net_stride + p.head_b_off;
+  float* out = acts + p.head_a_off + (long long)net * p.B * p.head_ld;
   for (int o = wave * 64 + lane; o < 32 * R * p.head_ld; o += 64 * NW) {
     const int row = o / p.head_ld, c = o - row * p.head_ld;
     if (row0 + row >= p.B) continue;
@@ -288,8 +293,14 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
   // XCD the weight stream thrashes L2 and falls back to the Infinity Cache.  Even XCD groups take net 0, odd ones
   // net 1, so each L2 keeps ONE net's weights resident.  (Speed only: any placement computes the same result.)
   int net, tile;
+  bool second = false;
   const int tiles = (p.B + 32 * R - 1) / (32 * R);
-  if (p.n_nets == 2 && (tiles & 3) == 0) {
+  if (p.pair) {   // (host side: n_nets == 2, tiles even) one (problem, net) weight set per XCD
+    const int b = blockIdx.x, g = b & 7, i = b >> 3;
+    second = g >= 4;
+    net = g & 1;
+    tile = i * 2 + ((g >> 1) & 1);
+  } else if (p.n_nets == 2 && (tiles & 3) == 0) {
     const int b = blockIdx.x, g = b & 7, i = b >> 3;
     net = g & 1;
     tile = i * 4 + (g >> 1);
@@ -297,10 +308,15 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
     net = blockIdx.x / tiles;
     tile = blockIdx.x % tiles;
   }
+  const float* __restrict__ pX = second ? p.X2 : p.X;
+  const float* __restrict__ pparams = second ? p.params2 : p.params;
+  const float* __restrict__ ppacked = second ? p.packed2 : p.packed;
+  float* __restrict__ pacts = second ? p.acts2 : p.acts;
+  const int pstash = second ? p.stash_all2 : p.stash_all;
   const int row0 = tile * 32 * R;
   const bool full_tile = row0 + 32 * R <= p.B;
   const int buf_ld4 = p.buf_ld >> 2;
-  const float4* packed_net = reinterpret_cast<const float4*>(p.packed + (long long)net * p.packed_net_stride);
+  const float4* packed_net = reinterpret_cast<const float4*>(ppacked + (long long)net * p.packed_net_stride);
   auto tpw_of = [](int ntiles) { return ntiles > 2 * NW ? 4 : ntiles > NW ? 2 : 1; };
   float4 bq[D][TM];
   // ring of layer 0, issued before the input tile is staged
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
     for (int l = 0; l < PQLK_MAX_LAYERS; ++l) {
       bv[l] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (l < p.n_hidden && tid < (p.dims[l + 1] >> 2))
-        bv[l] = reinterpret_cast<const float4*>(p.params + (long long)net * p.net_stride + p.b_off[l])[tid];
+        bv[l] = reinterpret_cast<const float4*>(pparams + (long long)net * p.net_stride + p.b_off[l])[tid];
     }
     const int k0 = (p.dims[0] + 31) & ~31, cpr = k0 >> 2, w = p.dims[0], total = 32 * R * cpr;
     // columns past the logical input width are forced to zero, so X may be a wider matrix whose extra columns hold
@@ -330,7 +346,7 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
         const int i = i0 + u * 64 * NW;
         const int row = i / cpr, c4 = i - row * cpr;
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < total && row0 + row < p.B) v[u] = *reinterpret_cast<const float4*>(p.X + (long long)(row0 + row) * p.ldx + 4 * c4);
+        if (i < total && row0 + row < p.B) v[u] = *reinterpret_cast<const float4*>(pX + (long long)(row0 + row) * p.ldx + 4 * c4);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -360,11 +376,11 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
     const bool last = l + 1 == p.n_hidden;
     // layer l's output goes to HBM either from its own epilogue (last hidden layer, ragged tiles) or from the next
     // layer's main loop (deferred: full tiles of a stashing forward)
-    const bool defer = p.stash_all && full_tile;
+    const bool defer = pstash && full_tile;
     // (a forward-only call whose output layer is fused needs no HBM copy of the last hidden layer at all)
-    const bool keep_last = last && (p.stash_all || p.head_n == 0);
-    float* gout = (keep_last || (p.stash_all && !full_tile)) ? p.acts + p.a_off[l] + (long long)net * p.B * N : nullptr;
-    float* gprev = (defer && l > 0) ? p.acts + p.a_off[l - 1] + (long long)net * p.B * p.dims[l] : nullptr;
+    const bool keep_last = last && (pstash || p.head_n == 0);
+    float* gout = (keep_last || (pstash && !full_tile)) ? pacts + p.a_off[l] + (long long)net * p.B * N : nullptr;
+    float* gprev = (defer && l > 0) ? pacts + p.a_off[l - 1] + (long long)net * p.B * p.dims[l] : nullptr;
     const int nprev4 = p.dims[l] >> 2;
     const float4* packed_n = last ? nullptr : packed_net + (p.p_off[l + 1] >> 2);
     const int K8n = last ? 1 : N >> 3, ntiles_n = last ? 1 : p.dims[l + 2] >> 5;
@@ -383,7 +399,7 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
       fused_layer<R, 1, TM, D>(bq, buf_ld4, K8, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n, ntiles_n,
                                tpw_n, gprev, nprev4 FP_CLKARG);
   }
-  if (p.head_n > 0) fused_head<R>(p, net, row0, buf_ld4, wave, lane);   // the LDS buffer holds the last hidden layer's output
+  if (p.head_n > 0) fused_head<R>(p, pparams, pacts, net, row0, buf_ld4, wave, lane);   // the LDS buffer holds the last hidden layer's output
 }
 
 // arena -> fragment-ordered copy of the hidden layers' weights (one thread per element; 1-3 M elements); ONE launch for all
