@@ -258,10 +258,14 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
                                                             float eps, int clamp5, float* __restrict__ x_sa, int64_t ld_sa,
                                                             float* __restrict__ xn_sa, float* __restrict__ xn_obs, int64_t ld_o,
                                                             float* __restrict__ o_rew, float* __restrict__ o_done, int write_pads,
-                                                            int nt_loads) {
+                                                            int nt_loads, int halves) {
   typedef float f4n __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63;
-  const int c = lane << 2;
+  // halves == 2: records of 1-2 KiB (cfg #4: 1792 B) -- the odd waves of a block take the second KiB of the rows the even waves
+  // take the first of, so a lane still owns ONE 16-B chunk and its plan
+  const int half = halves == 2 ? (threadIdx.x >> 6) & 1 : 0;
+  const int cl = lane + 64 * half;   // this lane's chunk of the record
+  const int c = cl << 2;
   const int nchunk = L.used >> 2;
   // per-lane plan
   float* dstA = nullptr;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
   int ncol = -1;    // column of the normalisation constants, -1 = copy
   int nvalid = 4;   // logical elements in this chunk (< 4 only in a field's last chunk when O or A is not a multiple of 4)
   bool vecA = true, is_rd = false;
-  if (lane < nchunk) {
+  if (cl < nchunk) {
     if (c < L.o4) {
       dstA = x_sa ? x_sa + c : nullptr; ldA = ld_sa; ncol = c; nvalid = min(4, L.O - c);
     } else if (c < L.off_act) {
@@ -303,8 +307,8 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
   const int npad_sa = (int)(ld_sa - sa_cols), npad_o = xn_obs ? (int)(ld_o - L.O) : 0;
   const bool pad_vec = (sa_cols & 3) == 0 && (L.O & 3) == 0;
 
-  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const int64_t wave = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) / halves;
+  const int64_t nwaves = (int64_t)gridDim.x * 4 / halves;
   for (int64_t r0 = wave * R; r0 < b; r0 += nwaves * R) {
     float4 v[R];
 #pragma unroll
@@ -312,12 +316,12 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
       const int64_t r = r0 + i;
       int64_t src = r < b ? idx[r] : 0;
       if (src < 0 || src >= capacity) src = 0;
-      if (lane < nchunk) {
+      if (cl < nchunk) {
         if (nt_loads) {   // records are read once per sample: keep them out of the caches the output tiles will be read from
-          const f4n t = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(records + src * L.ld) + lane);
+          const f4n t = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(records + src * L.ld) + cl);
           v[i] = make_float4(t[0], t[1], t[2], t[3]);
         } else {
-          v[i] = reinterpret_cast<const float4*>(records + src * L.ld)[lane];
+          v[i] = reinterpret_cast<const float4*>(records + src * L.ld)[cl];
         }
       } else {
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
         if (o_rew) o_rew[r] = x.x;
         if (o_done) o_done[r] = x.y;
       }
-      if (!write_pads) continue;
+      if (!write_pads || half) continue;
       if (pad_vec) {   // pads start on a 16-B boundary: one 16-B zero store per lane
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lane < (npad_sa >> 2)) {
@@ -412,7 +416,7 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
   int64_t blocks = (b + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
   if (blocks > 2048) blocks = 2048;
   // aligned transition-ring shape -> lean kernel (pads: at most 64 16-B chunks in total, one lane each)
-  const bool fast = L.A >= 0 && nchunk <= 64 && (ld_sa - L.O - L.A) <= 64 && (!xn_obs || (ld_o - L.O) <= 64) &&
+  const bool fast = L.A >= 0 && nchunk <= 128 && (ld_sa - L.O - L.A) <= 64 && (!xn_obs || (ld_o - L.O) <= 64) &&
                     pqlk_aligned16(x_sa) && pqlk_aligned16(xn_sa) && pqlk_aligned16(xn_obs);
   if (fast) {
     // rows in flight per wave: 2 up to 16 Ki rows (more waves, shorter dependent idx -> row chain: 9.3 vs 10.5 us at 8192),
@@ -432,13 +436,15 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
     // bytes moved), not the way one wave's loads and stores queue.
     int R = 2;
     if (g_gather_R) R = g_gather_R;
-    int64_t fb = (b + 4 * R - 1) / (4 * R);
+    const int halves = nchunk > 64 ? 2 : 1;   // 1-2 KiB records: two waves per row
+    const int rows_blk = 4 / halves * R;
+    int64_t fb = (b + rows_blk - 1) / rows_blk;
     const int wpc = g_gather_waves_per_cu ? g_gather_waves_per_cu : 24;
     if (fb > 256 * (int64_t)wpc / 4) fb = 256 * (int64_t)wpc / 4;
     const dim3 g((unsigned)fb), t(256);
 #define PQLK_GATHER_FAST(NORM, RR) \
     hipLaunchKernelGGL((k_replay_gather_fast<NORM, RR>), g, t, 0, pqlk_s(stream), ring->records, L, ring->capacity, idx, b, mean, var, \
-                       eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done, write_pads, g_gather_nt)
+                       eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done, write_pads, g_gather_nt, halves)
 #define PQLK_GATHER_FAST_R(NORM) \
     do { if (R == 1) PQLK_GATHER_FAST(NORM, 1); else if (R == 2) PQLK_GATHER_FAST(NORM, 2); else if (R == 4) PQLK_GATHER_FAST(NORM, 4); \
          else PQLK_GATHER_FAST(NORM, 8); } while (0)
