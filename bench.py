@@ -328,12 +328,15 @@ def free_running(actor, v, p, env, cfg, device, n=160):
     def rate(fn, reps, per_call=1.0):
         for _ in range(4):
             fn()
-        sync_all(device, v.device, p.device)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        sync_all(device, v.device, p.device)
-        return per_call * reps / (time.perf_counter() - t0)
+        vals = []
+        for _ in range(3):   # median of three blocks: one host hiccup inside a 100-ms block reads as -10 %
+            sync_all(device, v.device, p.device)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            sync_all(device, v.device, p.device)
+            vals.append(per_call * reps / (time.perf_counter() - t0))
+        return sorted(vals)[1]
 
     out["v_grad_steps_per_s"] = rate(v.learn, n)
     out["p_grad_steps_per_s"] = rate(p.learn, n)
