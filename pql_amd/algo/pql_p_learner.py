@@ -50,7 +50,8 @@ class PQLPLearner:
             raise NotImplementedError("W&B artifact download is out of scope (no network); load a local state_dict instead")
         self.opt = _AdamState(self.actor.arena.data)
         self._fused = bool(_cfg_get(algo, "fused", True))
-        self._fused_tail = not self.dp and bool(_cfg_get(algo, "fused_tail", True))
+        self._fold_loss = bool(_cfg_get(algo, "fused_tail", True))   # see PQLVLearner
+        self._fused_tail = not self.dp and self._fold_loss
         self.pk_actor = PackedWeights(self.actor.layout, self.device) if self._fused else None
         self.pk_critic = None
         self.critic = None
@@ -164,7 +165,7 @@ class PQLPLearner:
         K = int(getattr(self.critic, "num_atoms", 1))
         z = getattr(self.critic, "z_atoms", None) if K > 1 else None
         tail = self._fused_tail   # see PQLVLearner._step_kernels
-        L.check(L.lib.pqlk_dpg_loss_owner(L.ptr(q), cl.ld_out, K, L.ptr(z), B, L.ptr(ws["dy_c"]), None if tail else L.ptr(self.loss_ring),
+        L.check(L.lib.pqlk_dpg_loss_owner(L.ptr(q), cl.ld_out, K, L.ptr(z), B, L.ptr(ws["dy_c"]), None if self._fold_loss else L.ptr(self.loss_ring),
                                           L.ptr(self.opt.step), LOSS_RING, L.ptr(ws["scratch"]), C.c_void_p(ws["owner"].data_ptr()), st))
         a_out = output_view(al, ws["acts_a"], B)  # (1, B, ld_a): tanh output, for the tanh' chain
         # dX-only chain through the frozen critic; with scalar Q heads it runs over the samples partitioned by the net that
@@ -193,11 +194,12 @@ class PQLPLearner:
 
     def _step_post(self, ws):
         algo = self.cfg.algo
-        if self._fused_tail:
+        if self._fold_loss:
             K = int(getattr(self.critic, "num_atoms", 1))
             apply_optimizer_fused(self.actor.layout, self.actor.arena.data, ws["grads"], self.opt, None, algo.actor_lr,
                                   algo.max_grad_norm, 0.0, self.pk_actor, None, ws["scratch"], L.lib.pqlk_loss_parts(ws["B"], K),
-                                  f32_recip(ws["B"], sign=-1.0), self.loss_ring, self.device)
+                                  f32_recip(ws["B"], sign=-1.0), self.loss_ring, self.device, norm_in_backward=self._fused_tail,
+                                  grad_scale=1.0 / self.world)
             return
         apply_optimizer(self.actor.arena.data, ws["grads"], self.opt, None, algo.actor_lr, algo.max_grad_norm, 0.0,
                         1.0 / self.world, self.device, layout=self.actor.layout, packed=self.pk_actor)

@@ -76,17 +76,19 @@ def apply_optimizer(arena, grads, st: _AdamState, target, lr, max_grad_norm, tau
 
 
 def apply_optimizer_fused(layout, arena, grads, st: _AdamState, target, lr, max_grad_norm, tau, packed, packed_target,
-                          loss_part, loss_parts, loss_scale, loss_ring, device):
-    """Tail of a fused single-GPU learner step: AdamW (+ Polyak + re-pack) whose launch also folds the loss partials into
-    the loss ring; the squared-norm partials and the step increment were left in `st.scratch` / `st.step` by
-    `pqlk_mlp_backward_norm`.  Same bits as apply_optimizer + the stand-alone folds, two launches fewer."""
+                          loss_part, loss_parts, loss_scale, loss_ring, device, norm_in_backward=True, grad_scale=1.0):
+    """Tail of a fused learner step: AdamW (+ Polyak + re-pack) whose launch also folds the loss partials into the loss ring.
+    norm_in_backward (single GPU): the squared-norm partials and the step increment were left in `st.scratch` / `st.step` by
+    `pqlk_mlp_backward_norm` -- same bits as apply_optimizer + the stand-alone folds, two launches fewer.  Data parallel
+    (norm_in_backward=False, grad_scale = 1 / world): the norm pass runs here, on the all-reduced gradient; one launch fewer."""
     mn = float(max_grad_norm) if max_grad_norm is not None else 0.0
     pk = packed.tensor if packed is not None else None
     pt = packed_target.tensor if packed_target is not None else None
     L.check(L.lib.pqlk_adamw_polyak_fused(C.byref(layout.desc), L.ptr(arena), L.ptr(grads), L.ptr(st.m), L.ptr(st.v), L.ptr(target),
-                                          L.ptr(pk), L.ptr(pt), 1.0, mn, float(lr), 0.9, 0.999, 1e-8, 1e-2, float(tau),
+                                          L.ptr(pk), L.ptr(pt), float(grad_scale), mn, float(lr), 0.9, 0.999, 1e-8, 1e-2, float(tau),
                                           L.ptr(st.step), L.ptr(st.gnorm), L.ptr(st.scratch),
-                                          int(L.lib.pqlk_mlp_norm_parts(C.byref(layout.desc))), L.ptr(loss_part), int(loss_parts),
+                                          int(L.lib.pqlk_mlp_norm_parts(C.byref(layout.desc))) if norm_in_backward else 0,
+                                          L.ptr(loss_part), int(loss_parts),
                                           float(loss_scale), L.ptr(loss_ring), LOSS_RING, L.stream(device)))
 
 
@@ -242,7 +244,8 @@ class PQLVLearner:
         self.pk_target = PackedWeights(self.critic.layout, self.device) if fused else None
         self.pk_actor = None
         self._fused = fused
-        self._fused_tail = not self.dp and bool(_cfg_get(algo, "fused_tail", True))
+        self._fold_loss = bool(_cfg_get(algo, "fused_tail", True))   # loss partials folded by the optimiser launch
+        self._fused_tail = not self.dp and self._fold_loss            # ... and the gradient norm's partials by backward's reduction
         self.actor = None
         self.memory = ReplayBuffer(capacity=int(algo.memory_size), obs_dim=self.obs_dim, action_dim=self.action_dim,
                                    device=self.device)
@@ -388,7 +391,7 @@ class PQLVLearner:
         # single GPU: the loss fold and the gradient-norm pass ride in launches that exist anyway (backward's slab
         # reduction, the optimiser); data parallel keeps them apart because the all-reduce sits in between
         tail = self._fused_tail
-        loss_out = None if tail else L.ptr(self.loss_ring)
+        loss_out = None if self._fold_loss else L.ptr(self.loss_ring)
         if algo.distl:
             L.check(L.lib.pqlk_c51_bce_loss(L.ptr(q), L.ptr(qt), cl.ld_out, int(algo.num_atoms), L.ptr(ws["rew"]),
                                             L.ptr(ws["done"]), L.ptr(self.critic.z_atoms), gamma_n, float(algo.v_min),
@@ -418,12 +421,12 @@ class PQLVLearner:
 
     def _step_post(self, ws):
         algo, dev = self.cfg.algo, self.device
-        if self._fused_tail:
+        if self._fold_loss:
             K = int(algo.num_atoms) if algo.distl else 1
             apply_optimizer_fused(self.critic.layout, self.critic.arena.data, ws["grads"], self.opt, self.critic_target.arena.data,
                                   algo.critic_lr, algo.max_grad_norm, algo.tau, self.pk_critic, self.pk_target, ws["scratch"],
                                   L.lib.pqlk_loss_parts(ws["B"], K), f32_recip(ws["B"], K) if K > 1 else f32_recip(ws["B"]),
-                                  self.loss_ring, dev)
+                                  self.loss_ring, dev, norm_in_backward=self._fused_tail, grad_scale=1.0 / self.world)
             return
         # optimiser + Polyak + refresh of the fragment-ordered weight copies (critic and target) in one launch pair
         apply_optimizer(self.critic.arena.data, ws["grads"], self.opt, self.critic_target.arena.data, algo.critic_lr,
