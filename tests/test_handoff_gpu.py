@@ -331,3 +331,46 @@ def test_composed_rollout_explore_env_vs_oracle():
     for _ in range(3):
         check(1, False)      # steady state: one block of N rows per call
     assert sum(x != 0 for x in len_win) > 10   # episodes did finish (mean length 6): the trackers were exercised
+
+
+def test_rollout_policy_forward_follows_every_way_its_weights_can_change():
+    """The rollout's fused policy forward reads a fragment-ordered COPY of the replica's weights.  It must follow the replica
+    however it changes: `set_actor` (fenced adoption), the reference idiom `pql_actor.actor = deepcopy(actor)` (train_pql.py:52,
+    109), and an in-place load between two `explore_env` calls; and it must equal the module's own (per-layer) forward."""
+    from copy import deepcopy
+    import detdata as dd
+    from pql_amd.algo.pql_actor import PQLActor
+    from pql_amd.envs.synthetic import create_task_env
+    from pql_amd.models.mlp import TanhMLPPolicy
+    from pql_amd.utils.cfg import load_cfg
+    dev = torch.device("cuda:0")
+    N, O, A = 256, 88, 16
+    cfg = load_cfg(["task=AllegroHand", f"num_envs={N}", "algo.v_learner_gpu=0", "algo.p_learner_gpu=0", "algo.num_gpus=1",
+                    "sim_device=cuda:0", "device=cuda:0"])
+    actor = PQLActor(create_task_env(cfg), cfg)
+    actor.reset_agent()
+
+    def policy(seed):
+        m = TanhMLPPolicy((O,), A).to(dev)
+        m.load_state_dict({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in dd.mlp_state(O, A, seed).items()})
+        return m
+
+    obs = torch.from_numpy(dd.uniform((N, O), 5, -2, 2)).to(dev)
+
+    def check(module, what):
+        got = actor.get_actions(obs, sample=False)
+        with torch.no_grad():
+            want = module(actor.obs_rms.normalize(obs))
+        assert actor._pk is not None and actor._pk.tensor is not None, "fused policy forward not in use"
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=what)
+
+    a, b, c = policy(17), policy(18), policy(19)
+    actor.set_actor(a); check(a, "set_actor (first)")
+    actor.set_actor(b); check(b, "set_actor (adoption into the replica)")
+    actor.actor = deepcopy(c); check(c, "assignment of .actor")
+    actor.actor.load_state_dict(a.state_dict())          # in place: picked up by the next explore_env call
+    actor.explore_env(actor.env, 4, random=False)         # (the first call must span the n-step window)
+    obs = torch.from_numpy(dd.uniform((N, O), 6, -2, 2)).to(dev)
+    check(a, "in-place load before explore_env")
+    with torch.no_grad():
+        assert not torch.allclose(a(obs), b(obs))        # the policies do differ
