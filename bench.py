@@ -65,12 +65,19 @@ def parse():
     ap.add_argument("--no-fused", action="store_true", help="per-layer GEMM launches instead of the fused hidden-layer forward")
     ap.add_argument("--no-fused-tail", action="store_true", help="separate loss-fold / gradient-norm launches (A/B of algo.fused_tail)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true",
+                    help="skip the roofline / free-running sections after the timed blocks (rocprofv3 kernel-trace runs: the CSV's "
+                         "call counts then equal steps x launches per step; use with --burn-in-ms 0)")
     ap.add_argument("--cpu-steps", type=int, default=96, help="schedule steps of the bounded CPU-oracle sample (~15 s)")
     ap.add_argument("--v-only", action="store_true", help="time free-running V-learner steps only")
     ap.add_argument("--p-only", action="store_true", help="time free-running P-learner steps only (profiling)")
     ap.add_argument("--layout", default="dp", choices=["dp", "split2"],
                     help="N>1: dp = one rank per GPU, env/replay shards + RCCL gradient all-reduce; split2 = simulator on GPU 0, "
                          "both learners on GPU 1 (BASELINE configs[2])")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1 data parallel: weak = --num-envs / --replay / --batch are PER RANK (the job grows with N; `value` counts "
+                         "batch-sized steps summed over ranks); strong = they are the JOB's sizes and every rank takes 1/N of each "
+                         "(BASELINE configs[3] as written: --num-envs 16384 --gpus 8 = 2048 envs per rank)")
     ap.add_argument("--repeat", type=int, default=5, help="timed blocks of --steps steps; `value` is the FIRST block, "
                                                           "median/min/max over all blocks are reported beside it")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); 'gloo' + --share-gpu rehearses the DP path on one GPU")
@@ -106,10 +113,16 @@ def build_system(args, rank, world, device, pg, learner_device=None):
     cfg.algo.hidden_layers = hidden
     cfg.algo.fused_tail = not getattr(args, "no_fused_tail", False)
     cfg.algo.reward_scale = 0.01   # preprocess_cfg's AllegroHand value (common.py:159-170)
-    env = create_task_env(cfg, env_offset=rank * args.num_envs)
-    actor = PQLActor(env, cfg, env_offset=rank * args.num_envs, total_envs=world * args.num_envs)
-    v = PQLVLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=pg)
-    p = PQLPLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=pg)
+    sh = getattr(args, "shard", None)
+    env_offset = sh.env_offset if sh is not None else rank * args.num_envs
+    total_envs = sh.total_envs if sh is not None else world * args.num_envs
+    env = create_task_env(cfg, env_offset=env_offset)
+    actor = PQLActor(env, cfg, env_offset=env_offset, total_envs=total_envs)
+    # one communicator per collective-issuing component, so the three queues do not serialise on one internal RCCL stream
+    from pql_amd.utils.dp import component_groups
+    groups = component_groups(pg)
+    v = PQLVLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=groups["v"])
+    p = PQLPLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=groups["p"])
     if pg is not None:   # replicated parameters: every rank starts from rank 0's weights
         for t in (v.critic.arena.data, p.actor.arena.data):
             if torch.distributed.get_backend(pg) == "gloo":
@@ -117,7 +130,7 @@ def build_system(args, rank, world, device, pg, learner_device=None):
             else:
                 torch.distributed.broadcast(t, src=0, group=pg)
         v.critic_target.arena.data.copy_(v.critic.arena.data)
-        actor.obs_rms.pg = pg
+        actor.obs_rms.pg = groups["rms"]
     return cfg, env, actor, v, p
 
 
@@ -166,7 +179,7 @@ def sync_all(*devices):
 
 
 class Schedule:
-    """The 1 : 2 : 8 slice schedule (env : P : V).  Hand-offs go through the learners' `update()` exactly as in
+    """The design schedule: 1 env iteration : 4 P-steps : 8 V-steps (critic_sample_ratio 8, critic_actor_ratio 2).  Hand-offs go through the learners' `update()` exactly as in
     scripts/train_pql.py: event-fenced, double-buffered, snapshots of the weights (pql_amd/utils/handoff.py)."""
 
     def __init__(self, actor, v, p, env, cfg, device, critic, policy, mode="schedule"):
@@ -346,6 +359,52 @@ def free_running(actor, v, p, env, cfg, device, n=160):
     return out
 
 
+def free_running_concurrent(actor, v, p, env, cfg, device, critic, policy, seconds=2.0):
+    """SURVEY 8(d) "free-running (sleep times forced 0)": the reference's topology with nobody sleeping -- both learners pump
+    `learn()` in their own threads (pql_v_learner.py:136-141) while this thread loops rollout -> update -> update -> set_actor
+    (train_pql.py:100-119) as fast as it can, all three CONCURRENTLY on the GPU.  Rates = counter deltas / wall time."""
+    import threading
+    from pql_amd.algo.pql_p_learner import asyn_p_learner
+    from pql_amd.algo.pql_v_learner import asyn_v_learner
+    stop = threading.Event()
+    threads = [threading.Thread(target=asyn_v_learner, args=(v, cfg, stop, 2), daemon=True),
+               threading.Thread(target=asyn_p_learner, args=(p, cfg, stop, 2), daemon=True)]
+    v.sleep_time = p.sleep_time = 0
+    for t in threads:
+        t.start()
+    rms = actor.obs_rms
+
+    def iteration():
+        nonlocal critic, policy
+        actor.set_actor(policy)
+        p_data, v_data, n = actor.explore_env(env, int(cfg.algo.horizon_len), random=False)
+        critic, _, _ = v.update(policy, v_data, rms.get_states(v.device), 0)
+        policy, _, _ = p.update(critic, p_data, rms.get_states(p.device), 0)
+        return n
+
+    t_end = time.perf_counter() + 0.3   # let the threads reach steady state
+    while time.perf_counter() < t_end:
+        iteration()
+    sync_all(device, v.device, p.device)
+    v0, p0, env_steps, iters = v.update_count, p.update_count, 0, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        env_steps += iteration()
+        iters += 1
+        # (the rollout is host-bound at ~0.2 ms per iteration and would otherwise run hundreds of iterations ahead of the GPU)
+        if iters % 8 == 0:
+            torch.cuda.current_stream(device).synchronize()
+    stop.set()
+    for t in threads:
+        t.join()
+    sync_all(device, v.device, p.device)
+    dt = time.perf_counter() - t0
+    return {"v_grad_steps_per_s": (v.update_count - v0) / dt, "p_grad_steps_per_s": (p.update_count - p0) / dt,
+            "env_steps_per_s": env_steps / dt, "rollout_iterations_per_s": iters / dt, "seconds": dt,
+            "note": "V-learner, P-learner (threads) and rollout + hand-offs (this thread) all free-running at once, no sleeps, no "
+                    "ratio control; not part of `value`"}
+
+
 def cpu_baseline(args, O, A, hidden):
     """The CPU oracle (port of the reference learner, pinned to the reference by tests/golden) on this host's
     cores, same schedule, bounded sample."""
@@ -463,6 +522,11 @@ def main():
         if torch.distributed.get_world_size(pg) != world:
             raise SystemExit(f"process group has {torch.distributed.get_world_size(pg)} ranks, expected {world}")
     torch.manual_seed(42 + rank)
+    # data-parallel shard of this rank (pql_amd/utils/dp.py); from here on args.num_envs / replay / batch are PER RANK
+    from pql_amd.utils.dp import shard
+    args.shard = shard(args.num_envs, args.replay, args.batch, world, rank, args.scaling if world > 1 else "weak")
+    args.num_envs, args.replay, args.batch = args.shard.num_envs, args.shard.memory_size, args.shard.batch_size
+    strong = args.shard.scaling == "strong"
 
     def note(msg):
         if rank == 0:
@@ -514,8 +578,11 @@ def main():
     O, A = env.obs_dim, env.act_dim
     out_c = 51 if args.distl else 1
     f_v, f_p = flops_per_step(O, A, hidden, out_c, args.batch)
-    value = world * args.steps / dt
-    rates = sorted(world * args.steps / t for t in blocks)
+    # weak: every rank steps its own batch-B problem -> B-sized gradient steps summed over ranks; strong: one step of the
+    # job's batch (B = N x B/N) per schedule step
+    per_step = 1 if strong else world
+    value = per_step * args.steps / dt
+    rates = sorted(per_step * args.steps / t for t in blocks)
     n_gpus = 1 if args.share_gpu else args.gpus
     if split:
         par = "split2 (simulator + rollout policy on GPU 0, V- and P-learner on GPU 1, copy-stream hand-offs over xGMI)"
@@ -526,10 +593,11 @@ def main():
     backend = torch.distributed.get_backend(pg) if pg is not None else None
     unit = {"schedule": "V-learner grad-steps/s", "v_only": "V-learner grad-steps/s", "p_only": "P-learner grad-steps/s"}[mode]
     line = {
-        "metric": "learner grad-steps/sec + env-steps/sec, 4096 envs batch 8192 (value = V-learner grad-steps/s at the 1:2:8 "
-                  "env:P:V schedule; batch-8192 steps summed over ranks)",
+        "metric": "learner grad-steps/sec + env-steps/sec, 4096 envs batch 8192 (value = V-learner grad-steps/s at the design schedule "
+                  "1 env-iteration : 4 P-steps : 8 V-steps -- critic_sample_ratio 8, critic_actor_ratio 2; weak scaling: batch-sized "
+                  "steps summed over ranks, strong scaling: steps of the job's batch)",
         "value": value, "unit": unit, "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"PQL {args.gpus}xMI355X"
                                f"{' per rank (data parallel, ' + ('RCCL' if backend == 'nccl' else str(backend)) + ' grad all-reduce)' if world > 1 else ''}"
@@ -540,14 +608,18 @@ def main():
                    "schedule": {"schedule": "1 env-iteration : 4 P-steps : 8 V-steps", "v_only": "v_only", "p_only": "p_only"}[mode],
                    "graph": not args.no_graph, "burn_in_ms": args.burn_in_ms, "streams": not args.no_streams, "fused_forward": not args.no_fused,
                    "parallelism": par, "layout": args.layout if args.gpus > 1 else "single", "ranks": world,
+                   "per_rank": {"num_envs": args.num_envs, "replay_rows": args.replay, "batch": args.batch},
+                   "job": {"num_envs": args.shard.total_envs, "replay_rows": args.replay * world, "batch": args.batch * world},
                    "backend": backend, "share_gpu": bool(args.share_gpu)},
         "repeats": {"blocks": len(blocks), "steps_per_block": args.steps, "median": rates[len(rates) // 2], "min": rates[0],
                     "max": rates[-1], "note": "`value` is the first block; same unit"},
         "p_grad_steps_per_s": value / int(cfg.algo.critic_actor_ratio) if mode == "schedule" else 0.0,
-        "env_steps_per_s": value / int(cfg.algo.critic_sample_ratio) * args.num_envs if mode == "schedule" else 0.0,
+        "env_steps_per_s": (args.steps / dt) / int(cfg.algo.critic_sample_ratio) * args.shard.total_envs if mode == "schedule" else 0.0,
         "gflop_per_v_step": f_v / 1e9, "gflop_per_p_step": f_p / 1e9,
     }
-    if rank == 0:
+    if rank == 0 and args.no_roofline:
+        print(json.dumps(line), flush=True)
+    elif rank == 0:
         traffic, traffic_src = {}, None
         import glob
         tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))   # committed rocprofv3 --pmc passes; newest tag
@@ -565,11 +637,13 @@ def main():
         line["roofline"] = {"bound": "mfma", "kernel": "k_gemm + k_mlp_fwd_fused (all fp32 v_mfma_f32_32x32x2 launches of one V-learner step)",
                             "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("mfma_family_per_v_step_bytes"),
-                            "traffic_note": "bytes at the L2<->fabric boundary per V step (FETCH_SIZE x2 + WRITE_SIZE, PMC passes in "
-                                            f"{traffic_src}); the family is MFMA-bound, not HBM-bound",
+                            "traffic_source": (f"committed profile {traffic_src}, NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / "
+                                               "WRITE_SIZE passes of the same command on an earlier box (FETCH_SIZE x2 + WRITE_SIZE at the "
+                                               "L2<->fabric boundary, per V step)") if traffic_src else None,
                             "ms_per_launch_group": ms,
                             "mfma_util": mfma_util,
-                            "mfma_util_note": f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) per kernel, counter pass in {mfma_src}"}
+                            "mfma_util_source": (f"committed profile {mfma_src}, NOT measured in this run: SQ_VALU_MFMA_BUSY_CYCLES / "
+                                                 "(GRBM_GUI_ACTIVE x 1024 SIMDs) per kernel") if mfma_src else None}
         # (schedule mode only: the --v-only / --p-only runs are the profiler's per-launch-group passes, tools/pmc_traffic.py)
         if mode == "schedule" and v._fused and v.pk_target is not None and v.pk_target.tensor is not None:
             dms = dominant_kernel_ms(v)
@@ -588,6 +662,7 @@ def main():
         note("roofline sections measured")
         if world == 1 and mode == "schedule":
             line["free_running"] = free_running(actor, v, p, env, cfg, device)
+            line["free_running_concurrent"] = free_running_concurrent(actor, v, p, env, cfg, device, sched.critic, sched.policy)
             note("free-running rates measured")
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args, O, A, hidden)

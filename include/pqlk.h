@@ -220,6 +220,19 @@ int pqlk_mlp_backward_norm(const PqlMlpDesc* d, const float* params, const float
                            float* ws, int64_t ws_floats, float* sumsq_part, int32_t* step_dev, pqlk_stream_t stream);
 int32_t pqlk_mlp_norm_parts(const PqlMlpDesc* d);
 
+/* Backward of a twin critic with scalar Q heads whose head pass forms dL/dQ itself: TD target y = r + (1-d) gamma^n
+ * min(Q1', Q2') and the twin MSE loss of pql_v_learner.py:104-108 (replaces pqlk_td_mse_loss + pqlk_mlp_backward[_norm]: one
+ * launch less, dL/dQ never goes through memory).  acts / acts_target: activation stashes of the online and the target
+ * forward (only the target's head output is read).  loss_part receives pqlk_td_head_loss_parts(d, b) partial sums of
+ * (Q - y)^2 over both nets: fold with scale 1 / b (pqlk_adamw_polyak_fused's loss_part).  sumsq_part / step_dev: both
+ * non-NULL = as pqlk_mlp_backward_norm, both NULL = as pqlk_mlp_backward.  PQLK_E_UNSUPPORTED unless n_nets == 2, one
+ * output, and the last hidden width is <= 1024. */
+int pqlk_mlp_backward_td(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                         const float* acts, const float* acts_target, const float* rew, const float* done, float gamma_n,
+                         float* loss_part, float* grads, int32_t splits, float* ws, int64_t ws_floats,
+                         float* sumsq_part, int32_t* step_dev, pqlk_stream_t stream);
+int32_t pqlk_td_head_loss_parts(const PqlMlpDesc* d, int64_t b);   /* 0: this layout cannot take pqlk_mlp_backward_td */
+
 /* Tuning hook of the replay gather (tools/bench_gather.py): rows in flight per wave (1, 2, 4, 8), resident waves per CU,
  * "skip the pad stores" and non-temporal record loads for the next launches (0 = automatic / off). */
 int pqlk_tune_gather(int rows_in_flight, int waves_per_cu, int nopad, int nt_loads);

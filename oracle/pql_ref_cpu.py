@@ -370,9 +370,18 @@ class VLearnerRef:
         self.norm = norm
 
     def learn(self, idx=None, draw=None, generator=None):
-        hp = self.hp
         if self.actor is None:
             return None
+        loss, grads = self.loss_and_grads(idx, draw, generator)
+        params = [*self.q1, *self.q2]
+        self.opt.apply(list(grads), self.hp.max_grad_norm)
+        polyak_ref([*self.t1, *self.t2], [p.detach() for p in params], self.hp.tau)
+        self.update_count += 1
+        return float(loss.detach())
+
+    def loss_and_grads(self, idx=None, draw=None, generator=None):
+        """The first half of learn(): critic loss and its gradient (what a data-parallel rank all-reduces)."""
+        hp = self.hp
         if idx is None:
             idx = torch.randint(self.ring.cur_capacity, size=(hp.batch_size,), generator=generator)
         obs, act, rew, nobs, done = self.ring.gather(idx)
@@ -396,12 +405,7 @@ class VLearnerRef:
         else:
             c1, c2 = twin_forward_ref(self.q1, self.q2, obs, act)
             loss = F.mse_loss(c1, tgt) + F.mse_loss(c2, tgt)
-        params = [*self.q1, *self.q2]
-        grads = torch.autograd.grad(loss, params)
-        self.opt.apply(list(grads), hp.max_grad_norm)
-        polyak_ref([*self.t1, *self.t2], [p.detach() for p in params], hp.tau)
-        self.update_count += 1
-        return float(loss.detach())
+        return loss, torch.autograd.grad(loss, [*self.q1, *self.q2])
 
 
 class PLearnerRef:

@@ -239,7 +239,7 @@ class PQLPLearner:
                     self._graph_post.replay()
             else:
                 self._draw_and_step(ws)
-        self.update_count += 1
+            self.update_count += 1   # under the lock (see PQLVLearner.learn)
         return self.sleep_time
 
     @torch.no_grad()

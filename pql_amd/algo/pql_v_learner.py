@@ -246,6 +246,7 @@ class PQLVLearner:
         self._fused = fused
         self._fold_loss = bool(_cfg_get(algo, "fused_tail", True))   # loss partials folded by the optimiser launch
         self._fused_tail = not self.dp and self._fold_loss            # ... and the gradient norm's partials by backward's reduction
+        self._td_in_head = bool(_cfg_get(algo, "td_in_head", True))   # TD target + MSE inside the head's backward launch
         self.actor = None
         self.memory = ReplayBuffer(capacity=int(algo.memory_size), obs_dim=self.obs_dim, action_dim=self.action_dim,
                                    device=self.device)
@@ -332,6 +333,9 @@ class PQLVLearner:
         ws["splits"] = default_splits(B)
         ws["bwd"] = torch.empty(cl.bwd_ws_floats(B, ws["splits"]), **f)
         ws["scratch"] = torch.zeros(2048, **f)
+        # scalar twin heads: TD target + MSE + dL/dQ are formed inside the head's backward pass (one launch less)
+        ws["td_parts"] = int(L.lib.pqlk_td_head_loss_parts(C.byref(cl.desc), B)) if (self._fold_loss and self._td_in_head
+                                                                                      and not self.cfg.algo.distl) else 0
         self._ws = ws
         self.repack()
         return ws
@@ -392,6 +396,17 @@ class PQLVLearner:
         # reduction, the optimiser); data parallel keeps them apart because the all-reduce sits in between
         tail = self._fused_tail
         loss_out = None if self._fold_loss else L.ptr(self.loss_ring)
+        if ws["td_parts"] > 0:
+            L.check(L.lib.pqlk_mlp_backward_td(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
+                                               L.ptr(ws["acts_c"]), L.ptr(ws["acts_t"]), L.ptr(ws["rew"]), L.ptr(ws["done"]), gamma_n,
+                                               L.ptr(ws["scratch"]), L.ptr(ws["grads"]), ws["splits"], L.ptr(ws["bwd"]),
+                                               ws["bwd"].numel(), L.ptr(self.opt.scratch) if tail else None,
+                                               L.ptr(self.opt.step) if tail else None, st))
+            if upto_backward:
+                return
+            self._allreduce_grads(ws)
+            self._step_post(ws)
+            return
         if algo.distl:
             L.check(L.lib.pqlk_c51_bce_loss(L.ptr(q), L.ptr(qt), cl.ld_out, int(algo.num_atoms), L.ptr(ws["rew"]),
                                             L.ptr(ws["done"]), L.ptr(self.critic.z_atoms), gamma_n, float(algo.v_min),
@@ -425,7 +440,7 @@ class PQLVLearner:
             K = int(algo.num_atoms) if algo.distl else 1
             apply_optimizer_fused(self.critic.layout, self.critic.arena.data, ws["grads"], self.opt, self.critic_target.arena.data,
                                   algo.critic_lr, algo.max_grad_norm, algo.tau, self.pk_critic, self.pk_target, ws["scratch"],
-                                  L.lib.pqlk_loss_parts(ws["B"], K), f32_recip(ws["B"], K) if K > 1 else f32_recip(ws["B"]),
+                                  ws["td_parts"] or L.lib.pqlk_loss_parts(ws["B"], K), f32_recip(ws["B"], K) if K > 1 else f32_recip(ws["B"]),
                                   self.loss_ring, dev, norm_in_backward=self._fused_tail, grad_scale=1.0 / self.world)
             return
         # optimiser + Polyak + refresh of the fragment-ordered weight copies (critic and target) in one launch pair
@@ -477,7 +492,7 @@ class PQLVLearner:
                     self._graph_post.replay()
             else:
                 self._draw_and_step(ws)
-        self.update_count += 1
+            self.update_count += 1   # under the lock: update() reads it together with the device loss ring (free-running threads)
         return self.sleep_time
 
     @torch.no_grad()

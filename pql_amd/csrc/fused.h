@@ -77,13 +77,20 @@ constexpr int FUSED_NW = 8;   // waves per block
 // one ring group: up to D reduction steps of 8, each consuming ring slot s and (REFILL) refilling it D steps ahead
 template <int R, int TPW, int TM, int D, bool REFILL>
 __device__ __forceinline__ void fused_group(f32x16f (&acc)[R][TPW], float4 (&bq)[D][TM], const float4* const (&wp)[TPW],
-                                            const float4* __restrict__ lds4, int abase, int buf_ld4, int k8, int K8, int steps) {
+                                            const float4* __restrict__ lds4, int abase, int buf_ld4, int k8, int K8, int steps,
+                                            float4 (&an)[R]) {
 #pragma unroll
   for (int s = 0; s < D; ++s) {
     if (s < steps) {
+      // The activation fragments run ONE reduction step ahead of the MFMAs that consume them (`an`, carried from step to step,
+      // clamped at the layer's end).  Read at the top of their own step, both waves of a SIMD finish a step's 16 MFMAs at about
+      // the same time and then both sit out the LDS latency with the matrix pipe idle: -3 % on every fused forward (round 3,
+      // tools/kbench.py: 124.5 -> 121.2 us target critic, 134.4 -> 130.1 stashing critic, 70.7 -> 68.6 actor).
       float4 a[R];
+      const int kq = min(k8 + s + 1, K8 - 1);
 #pragma unroll
-      for (int i = 0; i < R; ++i) a[i] = lds4[abase + 32 * i * buf_ld4 + 2 * (k8 + s)];
+      for (int i = 0; i < R; ++i) { a[i] = an[i]; an[i] = lds4[abase + 32 * i * buf_ld4 + 2 * kq]; }
+      __builtin_amdgcn_sched_barrier(0);   // keep the reads HERE, ahead of this step's MFMAs (hipcc sinks them to their use)
       // unconditional, clamped refill: straight-line code lets the compiler keep the other ring stages in flight behind
       // a counted s_waitcnt vmcnt(N); a branch here degrades every wait to vmcnt(0)
       const int kn = min(k8 + s + D, K8 - 1);
@@ -159,20 +166,23 @@ __device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, in
     const int K8full = K8 - (K8 % D);
     const int G = K8full / D;
     const bool rem = D > 4 && K8full < K8;   // K8 % D == 4 (K8 is a multiple of 4): ring slots 0..3 hold those steps
-    if (G > 1) fused_group<R, TPW, TM, D, true>(acc, bq, wp, lds4, abase, buf_ld4, 0, K8, D);   // peeled (see header)
+    float4 an[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) an[i] = lds4[abase + 32 * i * buf_ld4];
+    if (G > 1) fused_group<R, TPW, TM, D, true>(acc, bq, wp, lds4, abase, buf_ld4, 0, K8, D, an);   // peeled (see header)
     for (int g = 1; g < G - 1; ++g) {
       if (srow < srows) {   // deferred stash of the previous layer (see above): one coalesced 16-B store per group
         gprev4[(long long)srow * nprev4 + sc4] = lds4[srow * buf_ld4 + sc4];
         srow += sdq; sc4 += sdm;
         if (sc4 >= nprev4) { sc4 -= nprev4; ++srow; }
       }
-      fused_group<R, TPW, TM, D, true>(acc, bq, wp, lds4, abase, buf_ld4, g * D, K8, D);
+      fused_group<R, TPW, TM, D, true>(acc, bq, wp, lds4, abase, buf_ld4, g * D, K8, D, an);
     }
     if (G >= 1) {
-      if (rem) fused_group<R, TPW, TM, D, true>(acc, bq, wp, lds4, abase, buf_ld4, (G - 1) * D, K8, D);
-      else fused_group<R, TPW, TM, D, false>(acc, bq, wp, lds4, abase, buf_ld4, (G - 1) * D, K8, D);
+      if (rem) fused_group<R, TPW, TM, D, true>(acc, bq, wp, lds4, abase, buf_ld4, (G - 1) * D, K8, D, an);
+      else fused_group<R, TPW, TM, D, false>(acc, bq, wp, lds4, abase, buf_ld4, (G - 1) * D, K8, D, an);
     }
-    if (rem) fused_group<R, TPW, TM, D, false>(acc, bq, wp, lds4, abase, buf_ld4, K8full, K8, 4);
+    if (rem) fused_group<R, TPW, TM, D, false>(acc, bq, wp, lds4, abase, buf_ld4, K8full, K8, 4, an);
   }
   while (srow < srows) {   // what the main loop did not cover (idle waves, short reductions)
     gprev4[(long long)srow * nprev4 + sc4] = lds4[srow * buf_ld4 + sc4];

@@ -55,10 +55,30 @@ struct GemmP {
   const int* perm;
   const int* mn;
   int xcd_remap;      // set by launch_gemm when the grid divides into whole groups per XCD
+  int frag_ahead;     // LDS-DMA loop: MFMA operand fragments are read from LDS one whole stage ahead (set by launch_gemm)
 };
 
 #include "narrow.h"
 #include "minnet.h"
+
+// experiment switches of the current tuning round (tools/kbench.py); removed once a variant is chosen
+int g_pqlk_knob[16] = {};
+extern "C" int pqlk_debug_knob(int key, int value) {
+  if (key < 0 || key >= 16) return PQLK_E_RANGE;
+  g_pqlk_knob[key] = value;
+  return PQLK_OK;
+}
+__attribute__((constructor)) static void pqlk_knobs_from_env() {   // PQLK_KNOBS="k=v,k=v"
+  const char* e = getenv("PQLK_KNOBS");
+  while (e && *e) {
+    char* end = nullptr;
+    const long k = strtol(e, &end, 10);
+    if (!end || *end != '=') break;
+    const long v = strtol(end + 1, &end, 10);
+    if (k >= 0 && k < 16) g_pqlk_knob[k] = (int)v;
+    e = (*end == ',') ? end + 1 : nullptr;
+  }
+}
 
 #ifndef PQLK_PROBE_DMA_A   // tuning probes only (wrong results): leave one operand's DMA requests out of the k loop
 #define PQLK_PROBE_DMA_A true
@@ -237,7 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
   constexpr int PF_LPR = WN / 4, PF_RPI = 64 / PF_LPR, PF_N = 32 / PF_RPI;
   constexpr bool AUX_PF = DMA && MODE == MODE_DX && EPI == EPI_DELU;
   f4v hpre[AUX_PF ? MI : 1][AUX_PF ? PF_N : 1];
-  if constexpr (AUX_PF) {
+  if (AUX_PF && !p.frag_ahead) {   // (with the fragments a stage ahead the registers go to the second fragment set instead)
     const float* auxw = p.aux + (long long)g0 * p.sAux;
     const int prow = lane / PF_LPR, pc4 = lane % PF_LPR;
 #pragma unroll
@@ -382,6 +402,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
       PQLK_DMA(0);
       PQLK_DMA(1);
       PQLK_DMA(2);
+      if (p.frag_ahead) {
+        // ---- fragments one STAGE ahead.  In the loop below a wave reads a stage's operand fragments right behind the barrier that
+        // publishes the stage and its first MFMA waits out the LDS latency; the co-resident block is often at the same point.  Here
+        // the counted wait is one tile tighter (tile kt + 1 has landed at the top of iteration kt: two tiles of lead instead of
+        // three), so the 32 registers of tile kt + 1's fragments are filled WHILE tile kt's 32 MFMAs issue, into a second register
+        // set (the kernel used 166 of its 256 VGPRs); behind each barrier the MFMAs start at once.  Same k order: same bits.
+        float fa0[KT / 8][MI][4], fb0[KT / 8][NJ][4], fa1[KT / 8][MI][4], fb1[KT / 8][NJ][4];
+#define PQLK_LDF(STG, FA, FB)                                                                                                  \
+  do {                                                                                                                         \
+    const float* sa_ = smem + (STG) * STG_F;                                                                                   \
+    const float* sb_ = sa_ + SA_F;                                                                                             \
+    _Pragma("unroll") for (int k8 = 0; k8 < KT / 8; ++k8) {                                                                    \
+      _Pragma("unroll") for (int i = 0; i < MI; ++i) {                                                                         \
+        if (MODE == MODE_DW) {                                                                                                 \
+          _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                        \
+            FA[k8][i][t] = sa_[(8 * k8 + 4 * h + t) * A_RLD + ((wm + 32 * i + r) ^ (32 * h))];                                 \
+        } else {                                                                                                               \
+          const float4 v_ = *reinterpret_cast<const float4*>(sa_ + (wm + 32 * i + r) * KT + 4 * ((2 * k8 + h) ^ ((r >> 2) & 3))); \
+          FA[k8][i][0] = v_.x; FA[k8][i][1] = v_.y; FA[k8][i][2] = v_.z; FA[k8][i][3] = v_.w;                                  \
+        }                                                                                                                      \
+      }                                                                                                                        \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                                           \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                          \
+          FB[k8][j][t] = sb_[(8 * k8 + 4 * h + t) * B_RLD + ((wn + 32 * j + r) ^ (32 * h))];                                   \
+    }                                                                                                                          \
+  } while (0)
+#define PQLK_MMF(STG, FA, FB)                                                                                                  \
+  do {                                                                                                                         \
+    if (MODE == MODE_DW && bx == 0) {                                                                                          \
+      const float* sa_ = smem + (STG) * STG_F;                                                                                 \
+      constexpr int DBR = KT / (256 / BM);                                                                                     \
+      _Pragma("unroll") for (int rr = 0; rr < DBR; ++rr) {                                                                     \
+        const int row = (tid / BM) * DBR + rr;                                                                                 \
+        dbacc += sa_[row * A_RLD + ((tid % BM) ^ (((row >> 2) & 1) * 32))];                                                    \
+      }                                                                                                                        \
+    }                                                                                                                          \
+    _Pragma("unroll") for (int k8 = 0; k8 < KT / 8; ++k8)                                                                      \
+      _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                            \
+        _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                         \
+          _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                                       \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(FB[k8][j][t], FA[k8][i][t], acc[i][j], 0, 0, 0);                  \
+    __builtin_amdgcn_sched_barrier(0);   /* hipcc otherwise moves all but one MFMA behind the NEXT barrier, next to its reads */ \
+  } while (0)
+        PQLK_DMA_WAIT(2 * NI); __syncthreads();   // tile 0 has landed
+        PQLK_LDF(0, fa0, fb0);
+        for (int kt = 0; kt < nk; kt += 4) {
+          PQLK_DMA_WAIT(NI); __syncthreads(); PQLK_DMA(3); PQLK_LDF(1, fa1, fb1); PQLK_MMF(0, fa0, fb0);
+          PQLK_DMA_WAIT(NI); __syncthreads(); PQLK_DMA(0); PQLK_LDF(2, fa0, fb0); PQLK_MMF(1, fa1, fb1);
+          PQLK_DMA_WAIT(NI); __syncthreads(); PQLK_DMA(1); PQLK_LDF(3, fa1, fb1); PQLK_MMF(2, fa0, fb0);
+          PQLK_DMA_WAIT(NI); __syncthreads(); PQLK_DMA(2); PQLK_LDF(0, fa0, fb0); PQLK_MMF(3, fa1, fb1);
+        }
+#undef PQLK_LDF
+#undef PQLK_MMF
+      } else
       for (int kt = 0; kt < nk; kt += 4) {
         PQLK_DMA_WAIT(2 * NI); __syncthreads(); PQLK_DMA(3); compute(kt, 0);
         PQLK_DMA_WAIT(2 * NI); __syncthreads(); PQLK_DMA(0); compute(kt + 1, 1);
@@ -565,7 +639,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
           const int gcol = n0 + wn + 4 * pc4;
           if (EPI == EPI_DELU) {
             float4 h4;
-            if constexpr (AUX_PF) {
+            if (AUX_PF && !p.frag_ahead) {
               h4 = make_float4(hpre[i][it].x, hpre[i][it].y, hpre[i][it].z, hpre[i][it].w);
             } else {
               long long arow = grow;
@@ -742,6 +816,7 @@ static int launch_gemm(GemmP p, int gz, hipStream_t st) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dshmem);
         if (e != hipSuccess) return -(int)e;
       }
+      p.frag_ahead = (g_pqlk_knob[1] >> (MODE == MODE_DW ? 0 : 1)) & 1;   // knob 1: bit 0 = dW products, bit 1 = dX products
       hipLaunchKernelGGL((k_gemm<MODE, BM, BN, EPI, KT, true>), grid, dim3(256), dshmem, st, p);
       PQLK_LAUNCH_CHECK();
       return PQLK_OK;
@@ -1188,14 +1263,19 @@ extern "C" int32_t pqlk_mlp_norm_parts(const PqlMlpDesc* d) {
   return main_blocks + (head_is_fused(d) ? (int)((head_quads(d) + 3) / 4) : 0);
 }
 
+struct TdHead {   // the scalar twin-Q head forms dL/dQ itself (pqlk_mlp_backward_td)
+  const float* qt; const float* rew; const float* done; float gamma_n; float* loss_part;
+};
+
 static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
                              const float* acts, const float* dy, float* grads, int32_t splits, float* dx,
                              int64_t ld_dx, int32_t dx_col0, int32_t dx_cols, const float* dx_tanh_of,
                              int64_t ld_tanh, float* ws, int64_t ws_floats, float* sq_part, int32_t* step_dev,
-                             pqlk_stream_t stream) {
+                             pqlk_stream_t stream, const TdHead* td = nullptr) {
   int rc = desc_ok(d);
   if (rc) return rc;
-  PQLK_REQUIRE(params && x && acts && dy && ws, PQLK_E_NULL);
+  PQLK_REQUIRE(params && x && acts && (dy || td) && ws, PQLK_E_NULL);
+  if (td) PQLK_REQUIRE(grads && d->n_nets == 2 && d->dims[d->n_layers] == 1 && head_is_fused(d), PQLK_E_UNSUPPORTED);
   PQLK_REQUIRE(b > 0 && b < (1LL << 30), PQLK_E_SHAPE);
   PQLK_REQUIRE(ldx % 32 == 0 && ldx >= pqlk_ld(d->dims[0]), PQLK_E_ALIGN);
   PQLK_REQUIRE(grads || dx, PQLK_E_NULL);
@@ -1247,6 +1327,13 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
         q.C = dact[flip]; q.sC = b * ld_in;
         q.epi = SK_EPI_DELU;
         head_blocks = skinny_bwd_blocks(b, d->n_nets);
+        if (td) {
+          int64_t q_off, q_ld;
+          pqlk_mlp_act_offset(d, b, 0, L - 1, &q_off, &q_ld);
+          PQLK_REQUIRE(in_ld >= ld_in && q_ld == ld_out, PQLK_E_SHAPE);
+          q.td_q = acts + q_off; q.td_qt = td->qt; q.td_rew = td->rew; q.td_done = td->done;
+          q.td_gamma_n = td->gamma_n; q.td_two_over_b = 2.0f / (float)b; q.td_part = td->loss_part;
+        }
         rc = launch_skinny_bwd(q, d->n_nets, head_part, (long long)(net_stride - w_off), st);
         if (rc) return rc;
         cur_dy = dact[flip];
@@ -1447,6 +1534,33 @@ extern "C" int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const
                                  int64_t ld_tanh, float* ws, int64_t ws_floats, pqlk_stream_t stream) {
   return mlp_backward_impl(d, params, x, ldx, b, acts, dy, grads, splits, dx, ld_dx, dx_col0, dx_cols, dx_tanh_of, ld_tanh, ws,
                            ws_floats, nullptr, nullptr, stream);
+}
+
+// The V-learner's scalar-head step: TD target + twin MSE (pql_v_learner.py:104-108) are formed INSIDE the head's backward pass
+// (k_skinny_bwd<1, CH, true>), which reads Q and the target Q anyway: pqlk_td_mse_loss's launch disappears and dL/dQ never
+// goes through memory.  loss_part receives pqlk_td_head_loss_parts(d, b) partial sums of (Q - y)^2 (both nets), to be folded
+// with scale 1 / b.  sumsq_part / step_dev as in pqlk_mlp_backward_norm (both NULL: plain backward).  PQLK_E_UNSUPPORTED
+// unless d is a twin net with one output whose head takes the one-pass skinny kernel.
+extern "C" int pqlk_mlp_backward_td(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                                    const float* acts, const float* acts_target, const float* rew, const float* done, float gamma_n,
+                                    float* loss_part, float* grads, int32_t splits, float* ws, int64_t ws_floats,
+                                    float* sumsq_part, int32_t* step_dev, pqlk_stream_t stream) {
+  int rc = desc_ok(d);
+  if (rc) return rc;
+  PQLK_REQUIRE(acts_target && rew && done && loss_part && grads, PQLK_E_NULL);
+  PQLK_REQUIRE((sumsq_part == nullptr) == (step_dev == nullptr), PQLK_E_NULL);
+  PQLK_REQUIRE(b > 0, PQLK_E_SHAPE);
+  int64_t q_off, q_ld;
+  rc = pqlk_mlp_act_offset(d, b, 0, d->n_layers - 1, &q_off, &q_ld);
+  if (rc) return rc;
+  const TdHead td = {acts_target + q_off, rew, done, gamma_n, loss_part};
+  return mlp_backward_impl(d, params, x, ldx, b, acts, nullptr, grads, splits, nullptr, 0, 0, 0, nullptr, 0, ws, ws_floats, sumsq_part,
+                           step_dev, stream, &td);
+}
+
+extern "C" int32_t pqlk_td_head_loss_parts(const PqlMlpDesc* d, int64_t b) {
+  if (desc_ok(d) || b <= 0 || d->n_nets != 2 || d->dims[d->n_layers] != 1 || !head_is_fused(d)) return 0;   // 0: unsupported
+  return (int32_t)(skinny_bwd_blocks(b, d->n_nets) * d->n_nets);
 }
 
 // Same, and the gradient's squared-norm partials + the optimiser's step increment come out of the final reduction pass:

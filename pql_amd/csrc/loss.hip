@@ -6,20 +6,18 @@
 
 #define LOSS_MAX_BLOCKS 1024
 
-// sum `n` partials in fixed order with one block -> out[0] = scale * sum
+// sum `n` partials in fixed order with one block -> out[0] = scale * sum  (strided per-thread sums -> xor-shuffle tree per wave
+// -> the four waves in order: the order in which k_adamw folds the same partials when the loss rides in its launch)
 __global__ __launch_bounds__(256) void k_sum_partials(const float* __restrict__ part, int n, float scale,
                                                       float* __restrict__ out, const int32_t* __restrict__ slot_dev,
                                                       int ring_len) {
-  __shared__ float sh[256];
+  __shared__ float shw[4];
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) s += part[i];
-  sh[threadIdx.x] = s;
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = s;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) out[slot_dev ? (slot_dev[0] % ring_len) : 0] = sh[0] * scale;
+  if (threadIdx.x == 0) out[slot_dev ? (slot_dev[0] % ring_len) : 0] = ((shw[0] + shw[1]) + (shw[2] + shw[3])) * scale;
 }
 
 __device__ __forceinline__ float block_sum_256(float v) {

@@ -77,11 +77,10 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
                                                const float* __restrict__ part, int nparts, AdamC c,
                                                const int32_t* __restrict__ step_dev, float* __restrict__ gnorm_out,
                                                PackSpec ps, LossFold lf) {
-  __shared__ float sh[256];
-  __shared__ float s_coef, s_step_size, s_bc2_sqrt;
-  // The operands of this thread's first quad are requested BEFORE the norm / step-size preamble (a strided partial load, an
-  // 8-level LDS tree and two double-precision pow() on one thread: a few microseconds during which a block otherwise has
-  // nothing in flight, and most blocks only ever process one quad per thread).
+  __shared__ float shn[4], shl[4];
+  __shared__ float s_step_size, s_bc2_sqrt;
+  // The operands of this thread's first quad are requested BEFORE the norm / step-size preamble (most blocks only ever
+  // process one quad per thread, and a block otherwise has nothing in flight meanwhile).
   typedef float f4 __attribute__((ext_vector_type(4)));
   auto al16 = [](const void* q) { return (reinterpret_cast<unsigned long long>(q) & 15ull) == 0; };
   const bool vec = al16(p) && al16(g) && al16(m) && al16(v) && (!target || al16(target));
@@ -93,41 +92,35 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
     p4n = reinterpret_cast<f4*>(p)[q0]; m4n = reinterpret_cast<f4*>(m)[q0]; v4n = reinterpret_cast<f4*>(v)[q0];
     if (target) t4n = reinterpret_cast<f4*>(target)[q0];
   }
-  if (lf.part && blockIdx.x == 0) {   // block-uniform
-    float ls = 0.f;
-    for (int i = threadIdx.x; i < lf.n; i += 256) ls += lf.part[i];
-    sh[threadIdx.x] = ls;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) lf.ring[(step_dev[0] - 1) % lf.ring_len] = sh[0] * lf.scale;
-    __syncthreads();
-  }
-  // every block re-reduces the (<= 1024) partials in the same fixed order -> identical clip factor
-  float s = 0.f;
-  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    const float total = sqrtf(sh[0]) * c.grad_scale;  // norm of the scaled gradient
-    float coef = 1.f;
-    if (c.max_norm > 0.f) coef = fminf(c.max_norm / (total + 1e-6f), 1.f);  // clip_grad_norm_
-    s_coef = coef * c.grad_scale;
+  // Preamble, ONE barrier: every block re-reduces the (<= 2048) squared-norm partials in the same fixed order (strided
+  // per-thread sums -> xor-shuffle tree per wave -> the four waves in order) -> identical clip factor everywhere; the two
+  // double-precision pow() of the bias corrections run meanwhile on one lane of wave 1, and block 0 folds the pending loss
+  // partials the same way.  (Round 2's form -- an 8-level LDS tree with a barrier per level, then the pow() chain on thread
+  // 0, then another barrier -- kept every block idle for ~5 us of a 14-us launch.)
+  const bool fold = lf.part && blockIdx.x == 0;   // block-uniform
+  if (threadIdx.x == 64) {
     const int t = step_dev[0];
     const double bc1 = 1.0 - pow(c.b1d, (double)t);
     const double bc2 = 1.0 - pow(c.b2d, (double)t);
     s_step_size = (float)(c.lr / bc1);
     s_bc2_sqrt = (float)sqrt(bc2);
-    if (blockIdx.x == 0 && gnorm_out) gnorm_out[0] = total;
   }
+  float s = 0.f, ls = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  if (fold)
+    for (int i = threadIdx.x; i < lf.n; i += 256) ls += lf.part[i];
+  s = wave_sum(s);
+  if (fold) ls = wave_sum(ls);
+  if ((threadIdx.x & 63) == 0) { shn[threadIdx.x >> 6] = s; shl[threadIdx.x >> 6] = ls; }
   __syncthreads();
-  const float coef = s_coef, step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
+  const float total = sqrtf((shn[0] + shn[1]) + (shn[2] + shn[3])) * c.grad_scale;  // norm of the scaled gradient
+  float clipc = 1.f;
+  if (c.max_norm > 0.f) clipc = fminf(c.max_norm / (total + 1e-6f), 1.f);  // clip_grad_norm_
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (gnorm_out) gnorm_out[0] = total;
+    if (fold) lf.ring[(step_dev[0] - 1) % lf.ring_len] = ((shl[0] + shl[1]) + (shl[2] + shl[3])) * lf.scale;
+  }
+  const float coef = clipc * c.grad_scale, step_size = s_step_size, bc2_sqrt = s_bc2_sqrt;
   // one parameter: the arithmetic of torch's AdamW foreach kernels, op for op (per element, so the 16-B path below
   // produces the same bits as the scalar one)
   auto upd = [&](float gi, float& pi, float& mi, float& vi, float& ti) {

@@ -25,6 +25,12 @@ struct SkinnyP {
   int epi;            // fwd: EPI_NONE / EPI_TANH / EPI_TANH_NOISE ; dx: EPI_DELU / EPI_NONE
   int splits, rows_per_split;
   float noise_std, noise_clip;
+  // k_skinny_bwd<1, CH, true>: the scalar twin-Q head forms dL/dQ itself (TD target + MSE, pql_v_learner.py:104-108)
+  // instead of reading it from dY: td_q / td_qt = (2, M, ldy) online / target head outputs (column 0), td_rew / td_done = (M),
+  // td_part[block][group] = sum of (Q - y)^2 over the block's rows.
+  const float* td_q; const float* td_qt; const float* td_rew; const float* td_done;
+  float td_gamma_n, td_two_over_b;
+  float* td_part;
 };
 
 enum { SK_EPI_NONE = 0, SK_EPI_TANH = 2, SK_EPI_TANH_NOISE = 3, SK_EPI_DELU = 4 };
@@ -277,8 +283,9 @@ __global__ __launch_bounds__(256) void k_skinny_dw(SkinnyP p) {
 // (N x ldk weights, then ld(N) biases: the arena layout of the layer) in `part[block][group]`; the slab-reduction kernel
 // folds the blocks in index order (deterministic, no atomics).  NB = compile-time bound on N (register arrays).
 #define SKB_ROWS 64   // rows per block when that still gives every CU a block; halved (down to 16) otherwise
-template <int NB, int CH>
+template <int NB, int CH, bool TD = false>
 __global__ __launch_bounds__(256) void k_skinny_bwd(SkinnyP p, float* __restrict__ part, long long part_floats, int rows_per_block) {
+  static_assert(!TD || NB == 1, "the TD-fused head is the scalar Q head");
   extern __shared__ __attribute__((aligned(16))) float sk_lds[];   // W (N, K) | red[3] (N, K) | dbred[4][16]
   const int g = blockIdx.y;
   const int kq = p.K >> 2;
@@ -302,6 +309,7 @@ __global__ __launch_bounds__(256) void k_skinny_bwd(SkinnyP p, float* __restrict
 #pragma unroll
     for (int c = 0; c < CH; ++c) acc[n][c] = make_float4(0.f, 0.f, 0.f, 0.f);
   float dbacc = 0.f;   // lane n < N: sum of dY[:, n] over this wave's rows
+  float tdacc = 0.f;   // TD: sum of (Q - y)^2 over this wave's rows (same value in every lane)
   const int m_blk = blockIdx.x * rows_per_block;
   // rows m_blk + wave + 4 j, j = 0 .. rows_per_block / 4 - 1, taken RIF at a time: all RIF x CH activation loads and the RIF dY
   // loads of a group are requested before the first is used
@@ -320,7 +328,18 @@ __global__ __launch_bounds__(256) void k_skinny_bwd(SkinnyP p, float* __restrict
         const int q = lane + 64 * c;
         xv[u][c] = (ok && q < kq) ? *reinterpret_cast<const float4*>(X + (long long)m * p.ldx + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      dyl[u] = (ok && lane < p.N) ? dY[(long long)m * p.ldy + lane] : 0.f;
+      if constexpr (TD) {   // wave-uniform addresses: one request each
+        float dq = 0.f;
+        if (ok) {
+          const float t1 = p.td_qt[(long long)m * p.ldy], t2 = p.td_qt[((long long)p.M + m) * p.ldy];
+          const float y = p.td_rew[m] + ((1.f - p.td_done[m]) * p.td_gamma_n) * fminf(t1, t2);   // r + (1-d) gamma^n min Q'
+          dq = p.td_q[((long long)g * p.M + m) * p.ldy] - y;
+        }
+        tdacc += dq * dq;
+        dyl[u] = lane == 0 ? p.td_two_over_b * dq : 0.f;
+      } else {
+        dyl[u] = (ok && lane < p.N) ? dY[(long long)m * p.ldy + lane] : 0.f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < RIF; ++u) {
@@ -367,6 +386,7 @@ __global__ __launch_bounds__(256) void k_skinny_bwd(SkinnyP p, float* __restrict
         }
   }
   if (lane < 16) dbred[wave * 16 + lane] = dbacc;
+  if (TD && lane == 16) dbred[64 + wave] = tdacc;
   __syncthreads();
   if (wave == 0) {
     float* out = part + ((long long)blockIdx.x * gridDim.y + g) * part_floats;
@@ -388,6 +408,7 @@ __global__ __launch_bounds__(256) void k_skinny_bwd(SkinnyP p, float* __restrict
         }
     if (lane < p.ldc)   // ldc = pqlk_ld(N) <= 32: bias block with zero pad
       out[(long long)p.N * p.ldk + lane] = lane < p.N ? ((dbred[lane] + dbred[16 + lane]) + dbred[32 + lane]) + dbred[48 + lane] : 0.f;
+    if (TD && lane == 0) p.td_part[(long long)blockIdx.x * gridDim.y + g] = ((dbred[64] + dbred[65]) + dbred[66]) + dbred[67];
   }
 }
 
@@ -405,16 +426,16 @@ static inline int skinny_bwd_rows(int64_t m, int groups) {
 }
 static inline int skinny_bwd_blocks(int64_t m, int groups) { const int r = skinny_bwd_rows(m, groups); return (int)((m + r - 1) / r); }
 
-template <int NB, int CH>
+template <int NB, int CH, bool TD = false>
 static int launch_skinny_bwd_t(const SkinnyP& p, int groups, float* part, long long part_floats, hipStream_t st) {
-  const size_t sh = ((size_t)4 * p.N * p.K + 64) * sizeof(float);
+  const size_t sh = ((size_t)4 * p.N * p.K + 72) * sizeof(float);
   static PqlkPerDeviceOnce attr_once;
   if (attr_once.need()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skinny_bwd<NB, CH>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (4 * 4096 + 64) * (int)sizeof(float));   // N x K <= 16 x 256 floats
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skinny_bwd<NB, CH, TD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (4 * 4096 + 72) * (int)sizeof(float));   // N x K <= 16 x 256 floats
     if (e != hipSuccess) return -(int)e;
   }
-  hipLaunchKernelGGL((k_skinny_bwd<NB, CH>), dim3(skinny_bwd_blocks(p.M, groups), groups), dim3(256), sh, st, p, part, part_floats,
+  hipLaunchKernelGGL((k_skinny_bwd<NB, CH, TD>), dim3(skinny_bwd_blocks(p.M, groups), groups), dim3(256), sh, st, p, part, part_floats,
                      skinny_bwd_rows(p.M, groups));
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
@@ -422,6 +443,11 @@ static int launch_skinny_bwd_t(const SkinnyP& p, int groups, float* part, long l
 
 static int launch_skinny_bwd(const SkinnyP& p, int groups, float* part, long long part_floats, hipStream_t st) {
   const int ch = skinny_bwd_ch(p.K);
+  if (p.td_q) {   // TD-fused scalar head (the caller checked N == 1, two groups)
+    if (ch == 1) return launch_skinny_bwd_t<1, 1, true>(p, groups, part, part_floats, st);
+    if (ch == 2) return launch_skinny_bwd_t<1, 2, true>(p, groups, part, part_floats, st);
+    return launch_skinny_bwd_t<1, 4, true>(p, groups, part, part_floats, st);
+  }
   if (p.N == 1) {
     if (ch == 1) return launch_skinny_bwd_t<1, 1>(p, groups, part, part_floats, st);
     if (ch == 2) return launch_skinny_bwd_t<1, 2>(p, groups, part, part_floats, st);

@@ -15,6 +15,7 @@ and drive the same entry points directly on the arenas.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from collections import OrderedDict
 from collections.abc import Sequence
@@ -191,14 +192,36 @@ class FusedMLP(nn.Module):
                 lay.weight(self.arena.data, n, l).uniform_(-bound, bound)
                 lay.bias(self.arena.data, n, l).uniform_(-bound, bound)
 
+    @contextlib.contextmanager
+    def leased(self):
+        """Reads of this module's arena enqueued on the caller's CURRENT stream.  A *published* snapshot
+        (pql_amd.utils.handoff.ArenaPublisher: what a learner's `start()` / `update()` hand out) is filled on the learner's
+        own stream, and the host runs far ahead of the GPU: the caller's stream first waits for the snapshot's ready event,
+        and the publisher may not refill the slot before the reads enqueued inside this block have run.  A plain module
+        (no lease) follows the usual stream convention: nothing to do."""
+        from pql_amd.utils import handoff as H
+        lease = H.lease_of(self)
+        if lease is None or not self.arena.is_cuda:
+            yield
+            return
+        with H.LOCK:
+            st = torch.cuda.current_stream(self.arena.device)
+            if lease.ready is not None:
+                st.wait_event(lease.ready)
+            try:
+                yield
+            finally:
+                H.release(lease, st)
+
     # ---- reference-keyed (de)serialisation ---------------------------------------------------------
     def state_dict(self, *args, destination=None, prefix="", keep_vars=False, **kw):
         out = OrderedDict() if destination is None else destination
         lay = self.layout
-        for n, pre in enumerate(self.key_prefixes):
-            for l in range(lay.n_layers):
-                out[f"{prefix}{pre}{2 * l}.weight"] = lay.weight(self.arena.data, n, l).clone()
-                out[f"{prefix}{pre}{2 * l}.bias"] = lay.bias(self.arena.data, n, l).clone()
+        with self.leased():   # the clones are enqueued behind the snapshot's ready event (torch.save / evaluator specs of a snapshot)
+            for n, pre in enumerate(self.key_prefixes):
+                for l in range(lay.n_layers):
+                    out[f"{prefix}{pre}{2 * l}.weight"] = lay.weight(self.arena.data, n, l).clone()
+                    out[f"{prefix}{pre}{2 * l}.bias"] = lay.bias(self.arena.data, n, l).clone()
         return out
 
     @torch.no_grad()
@@ -252,7 +275,8 @@ class FusedMLP(nn.Module):
         return new
 
     def _run(self, x):
-        return FusedMlpFn.apply(x, self.arena, self.layout, self.out_act)
+        with self.leased():
+            return FusedMlpFn.apply(x, self.arena, self.layout, self.out_act)
 
 
 class MLPNet(FusedMLP):
@@ -296,7 +320,8 @@ class TanhDiagGaussianMLPPolicy(FusedMLP):
         L.require_gpu(self.arena, "parameter arena")
         x_pad = pad_cols(state.to(torch.float32), self.layout.ld_in)
         B, dev, A = x_pad.shape[0], x_pad.device, self.act_dim
-        y = output_view(self.layout, mlp_forward_raw(self.layout, self.arena.data, x_pad, L.ACT_NONE), B)[0]
+        with self.leased():
+            y = output_view(self.layout, mlp_forward_raw(self.layout, self.arena.data, x_pad, L.ACT_NONE), B)[0]
         act = torch.empty((B, A), dtype=torch.float32, device=dev)
         logp = torch.empty((B, 1), dtype=torch.float32, device=dev) if want_logp else None
         with torch.cuda.device(dev):

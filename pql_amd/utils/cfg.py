@@ -78,6 +78,10 @@ def _load_file(path: Path, group_choices=None):
             if group == "task" and not fpath.exists():
                 # the reference's `task=<IsaacGymEnvs task name>` (pql/cfg/default.yaml:7-9 + the isaacgymenvs search
                 # path): here every task is the synthetic vectorised env with that task's shapes
+                from pql_amd.envs.synthetic import TASK_SHAPES   # (torch-only module; imported here to keep cfg import light)
+                if str(option) not in TASK_SHAPES:   # a typo must fail at config load, as Hydra's missing-config error does
+                    raise ValueError(f"task={option}: no such task; known tasks: {', '.join(sorted(TASK_SHAPES))} "
+                                     f"(or task=synthetic with task.obs_dim / task.act_dim)")
                 sub = _load_file(path.parent / group / "synthetic.yaml")
                 sub["name"] = str(option)
             else:

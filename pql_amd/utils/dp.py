@@ -1,0 +1,67 @@
+"""Data-parallel layout of the PQL path: which slice of the job a rank owns, and which communicator each
+component's collectives ride on.
+
+The reference has no data parallelism (its three Ray actors share GPUs by function, scripts/train_pql.py:41-70); BASELINE
+configs[3] asks for it at 4/8 GPUs: envs are independent units, so rank r of G owns envs [r N/G, (r+1) N/G), the n-step
+windows of those envs, a replay shard of memory_size / G rows filled only from them, and draws batch_size / G samples per
+gradient step from it (equal shards -> the union of the draws is uniform over the global ring in distribution; the mean of
+the per-rank batch means is the global batch mean).
+
+    scaling = "strong"  the cfg's num_envs / memory_size / batch_size are the JOB's: each rank takes 1/G of each
+                        (BASELINE configs[3] as written: 16384 envs over 8 GPUs = 2048 per rank);
+    scaling = "weak"    they are PER RANK: the job grows with G (global batch G x 8192).
+
+Collectives: the V-learner's and the P-learner's gradient all-reduces and the rollout's running-statistics all-gather are
+issued from three different HIP streams.  On ONE torch process group they would all be funnelled through that group's one
+internal RCCL stream and serialise in issue order (a P all-reduce queued behind the V-learner's backward); each component
+therefore gets its own communicator (`component_groups`), so the three queues stay independent on the device while the
+issue order inside each communicator is the same on every rank (fixed-ratio loop)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class Shard:
+    world: int
+    rank: int
+    scaling: str
+    num_envs: int        # per rank
+    memory_size: int     # per rank
+    batch_size: int      # per rank
+    total_envs: int      # whole job
+    env_offset: int      # first global env id of this rank
+
+    @property
+    def global_batch(self):
+        return self.batch_size * self.world
+
+
+def shard(num_envs, memory_size, batch_size, world, rank, scaling="strong") -> Shard:
+    """Per-rank sizes.  Strong scaling refuses sizes that do not divide: a ragged split would make shards unequal, and with
+    unequal shards neither 'uniform over the union' nor 'mean of rank means == global mean' holds."""
+    num_envs, memory_size, batch_size, world, rank = int(num_envs), int(memory_size), int(batch_size), int(world), int(rank)
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"rank {rank} of world {world}")
+    if scaling == "weak" or world == 1:
+        return Shard(world, rank, "weak" if world > 1 else "single", num_envs, memory_size, batch_size, num_envs * world, rank * num_envs)
+    if scaling != "strong":
+        raise ValueError(f"scaling must be 'strong' or 'weak', got {scaling!r}")
+    for name, v in (("num_envs", num_envs), ("batch_size", batch_size)):
+        if v % world:
+            raise ValueError(f"{name}={v} does not divide over {world} ranks (strong scaling needs equal shards)")
+    per_mem = memory_size // world   # rows; a remainder of < world rows of capacity is dropped, every shard equal
+    if per_mem < 1:
+        raise ValueError(f"memory_size={memory_size} is smaller than the world size {world}")
+    return Shard(world, rank, "strong", num_envs // world, per_mem, batch_size // world, num_envs, rank * (num_envs // world))
+
+
+def component_groups(pg, names=("v", "p", "rms")):
+    """One communicator per collective-issuing component.  Every rank must call this at the same point (new_group is itself
+    collective).  pg None -> {name: None}."""
+    if pg is None:
+        return {n: None for n in names}
+    import torch.distributed as dist
+    backend = dist.get_backend(pg)
+    ranks = dist.get_process_group_ranks(pg)
+    return {n: dist.new_group(ranks=ranks, backend=backend) for n in names}

@@ -16,7 +16,10 @@ the design ratios 1 : critic_sample_ratio : critic_sample_ratio / critic_actor_r
       pql_amd.utils.ratio_control.RatioController) tells whoever is too fast how long to sleep per unit.
 
 With torchrun (WORLD_SIZE > 1) the env axis and the replay shard data-parallel and gradients are all-reduced over
-RCCL (fixed-ratio loop only: free-running ranks would issue their collectives out of step).
+RCCL (fixed-ratio loop only: free-running ranks would issue their collectives out of step).  `algo.dp_global=True`
+(default) reads num_envs / algo.memory_size / algo.batch_size as the JOB's sizes and gives every rank 1/G of each, so
+BASELINE configs[3] (`num_envs=16384` on 8 GPUs) runs as written; `algo.dp_global=False` reads them per rank (weak scaling).
+V-learner, P-learner and the running statistics each get their own RCCL communicator (pql_amd/utils/dp.py).
 """
 import os
 import sys
@@ -35,6 +38,7 @@ from pql_amd.algo.pql_v_learner import PQLVLearner, asyn_v_learner  # noqa: E402
 from pql_amd.envs.synthetic import create_task_env  # noqa: E402
 from pql_amd.utils.cfg import load_cfg  # noqa: E402
 from pql_amd.utils.common import capture_keyboard_interrupt, preprocess_cfg, set_random_seed  # noqa: E402
+from pql_amd.utils.dp import component_groups, shard  # noqa: E402
 from pql_amd.utils.evaluator import Evaluator  # noqa: E402
 from pql_amd.utils.logger import MetricLogger  # noqa: E402
 from pql_amd.utils.ratio_control import RatioController  # noqa: E402
@@ -62,6 +66,10 @@ def main(cfg):
         cfg.device = cfg.sim_device = cfg.rl_device = f"cuda:{local}"
         cfg.algo.v_learner_gpu = cfg.algo.p_learner_gpu = local
         cfg.algo.num_gpus = 1
+    sh = shard(cfg.num_envs, cfg.algo.memory_size, cfg.algo.batch_size, world, rank,
+               "strong" if bool(cfg.algo.get("dp_global", True)) else "weak")
+    cfg.num_envs, cfg.algo.memory_size, cfg.algo.batch_size = sh.num_envs, sh.memory_size, sh.batch_size
+    groups = component_groups(pg)   # (collective: every rank, same point)
     if cfg.algo.num_gpus == 1 and world == 1:
         cfg.algo.v_learner_gpu = 0
         cfg.algo.p_learner_gpu = 0
@@ -70,20 +78,24 @@ def main(cfg):
     preprocess_cfg(cfg)
     capture_keyboard_interrupt()
     set_random_seed(cfg.seed + rank)
-    env = create_task_env(cfg, env_offset=rank * cfg.num_envs)
+    env = create_task_env(cfg, env_offset=sh.env_offset)
     sim_device = torch.device(cfg.sim_device)
     v_dev = torch.device(f"cuda:{cfg.algo.v_learner_gpu}")
     p_dev = torch.device(f"cuda:{cfg.algo.p_learner_gpu}")
 
-    pql_actor = PQLActor(env, cfg, env_offset=rank * cfg.num_envs, total_envs=world * cfg.num_envs)
-    v_learner = PQLVLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=pg)
-    p_learner = PQLPLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=pg)
+    if cfg.algo.num_gpus > 1 and world == 1 and v_dev != sim_device and not torch.cuda.can_device_access_peer(v_dev.index, sim_device.index):
+        # torch's cross-device copy_ then stages through host memory and synchronises: the copy-stream hand-offs still work,
+        # but the "learner stream never waits for the link" property is gone -- say so instead of degrading silently
+        print(f"[train_pql] warning: {sim_device} and {v_dev} have no peer access; hand-offs will be host-staged", file=sys.stderr)
+    pql_actor = PQLActor(env, cfg, env_offset=sh.env_offset, total_envs=sh.total_envs)
+    v_learner = PQLVLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=groups["v"])
+    p_learner = PQLPLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=groups["p"])
     if world > 1:
         for t in (v_learner.critic.arena.data, p_learner.actor.arena.data):
             torch.distributed.broadcast(t, src=0, group=pg)
         v_learner.critic_target.arena.data.copy_(v_learner.critic.arena.data)
         if pql_actor.obs_rms is not None:
-            pql_actor.obs_rms.pg = pg
+            pql_actor.obs_rms.pg = groups["rms"]
     critic, critic_update_times, critic_loss = v_learner.start()
     actor, actor_update_times, actor_loss = p_learner.start()
     pql_actor.set_actor(actor)

@@ -136,3 +136,90 @@ def test_mixed_noise_uses_global_env_index():
     torch.manual_seed(2); whole = add_mixed_normal_noise(torch.zeros(8, 2), 0.8, 0.05)
     torch.manual_seed(2); draw = torch.empty(8, 2).normal_()
     assert torch.allclose(whole, draw * std.unsqueeze(1))                    # single-GPU form unchanged
+
+
+# --------------------------------------------------------------------------- shard sizes (strong / weak) and communicators
+def test_shard_sizes_strong_and_weak():
+    from pql_amd.utils.dp import shard
+    # BASELINE configs[3] as written: 16384 envs, replay 5 M, batch 8192 over 8 GPUs
+    parts = [shard(16384, 5_000_000, 8192, 8, r, "strong") for r in range(8)]
+    assert all((p.num_envs, p.memory_size, p.batch_size, p.total_envs) == (2048, 625_000, 1024, 16384) for p in parts)
+    assert [p.env_offset for p in parts] == [2048 * r for r in range(8)] and parts[0].global_batch == 8192
+    w = shard(4096, 1_000_000, 8192, 4, 3, "weak")
+    assert (w.num_envs, w.memory_size, w.batch_size, w.total_envs, w.env_offset, w.global_batch) == (4096, 1_000_000, 8192, 16384, 12288, 32768)
+    one = shard(4096, 1_000_000, 8192, 1, 0, "strong")
+    assert (one.num_envs, one.batch_size, one.scaling) == (4096, 8192, "single")
+    with pytest.raises(ValueError, match="num_envs"):
+        shard(4097, 1_000_000, 8192, 2, 0, "strong")
+    with pytest.raises(ValueError, match="batch_size"):
+        shard(4096, 1_000_000, 8191, 2, 0, "strong")
+
+
+def _groups(rank, world):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pql_amd.utils.dp import component_groups
+    g = component_groups(dist.group.WORLD)
+    assert len({id(x) for x in g.values()}) == 3 and all(dist.get_world_size(x) == world for x in g.values())
+    # collectives issued in a DIFFERENT order per group on the two ranks still pair up: the groups are independent queues
+    order = ("v", "p", "rms") if rank == 0 else ("rms", "p", "v")
+    vals = {n: torch.full((4,), float(10 * i + rank + 1)) for i, n in enumerate(("v", "p", "rms"))}
+    works = [dist.all_reduce(vals[n], group=g[n], async_op=True) for n in order]
+    for w in works:
+        w.wait()
+    return np.stack([vals[n].numpy() for n in ("v", "p", "rms")])
+
+
+def test_component_groups_are_independent_communicators():
+    a, b = run2(_groups)
+    want = np.stack([np.full(4, 20.0 * i + 3.0) for i in range(3)])   # (10 i + 1) + (10 i + 2)
+    assert np.array_equal(a, want) and np.array_equal(b, want)
+
+
+def _strong_half_steps(rank, world):
+    """Two ranks in STRONG mode: each owns half the envs' rows of a sharded ring and half the batch; the all-reduced mean
+    gradient and the replicated optimiser step must reproduce the one-process step on the whole batch."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import pql_ref_cpu as ref
+    from pql_amd.utils.dp import shard
+    O, A, B, rows = 8, 2, 64, 96
+    sh = shard(32, 2 * rows, B, world, rank, "strong")
+    assert (sh.memory_size, sh.batch_size) == (rows, B // 2)
+    cst, ast = dd.doubleq_state(O, A, 1, 21), dd.mlp_state(O, A, 11)
+    hp = ref.HyperRef(batch_size=sh.batch_size)
+    v = ref.VLearnerRef(O, A, hp, sh.memory_size, ref.params_from_state(cst, "net_q1.net."), ref.params_from_state(cst, "net_q2.net."))
+    whole = (T(dd.uniform((2 * rows, O), 1, -3, 3)), T(dd.uniform((2 * rows, A), 2)), T(dd.uniform((2 * rows, 1), 3, -0.05, 0.05)),
+             T(dd.uniform((2 * rows, O), 4, -3, 3)), T(dd.bernoulli((2 * rows, 1), 5, 0.1)))
+    mine = tuple(t[rank * rows:(rank + 1) * rows] for t in whole)          # this rank's envs' transitions -> its ring shard
+    mean, var = T(dd.uniform((O,), 6, -0.5, 0.5)), T(dd.uniform((O,), 7, 0.5, 2.0))
+    v.update(ref.params_from_state(ast), mine, (mean, var, 1e-4))
+    idx_local = T(dd.integers((sh.batch_size,), 8 + rank, rows))           # B/G uniform draws from the shard
+    draw = T(dd.uniform((B, A), 9, -2, 2))[rank * sh.batch_size:(rank + 1) * sh.batch_size]
+    loss, grads = v.loss_and_grads(idx=idx_local, draw=draw)
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
+    flat *= 1.0 / world
+    return flat.numpy(), float(loss.detach())
+
+
+def test_strong_scaling_two_ranks_reproduce_the_one_process_gradient():
+    from oracle import pql_ref_cpu as ref
+    if not hasattr(ref.VLearnerRef, "loss_and_grads"):
+        pytest.skip("oracle has no loss_and_grads")
+    (g0, l0), (g1, l1) = run2(_strong_half_steps)
+    assert np.array_equal(g0, g1)
+    O, A, B, rows = 8, 2, 64, 96
+    cst, ast = dd.doubleq_state(O, A, 1, 21), dd.mlp_state(O, A, 11)
+    hp = ref.HyperRef(batch_size=B)
+    v = ref.VLearnerRef(O, A, hp, 2 * rows, ref.params_from_state(cst, "net_q1.net."), ref.params_from_state(cst, "net_q2.net."))
+    whole = (T(dd.uniform((2 * rows, O), 1, -3, 3)), T(dd.uniform((2 * rows, A), 2)), T(dd.uniform((2 * rows, 1), 3, -0.05, 0.05)),
+             T(dd.uniform((2 * rows, O), 4, -3, 3)), T(dd.bernoulli((2 * rows, 1), 5, 0.1)))
+    mean, var = T(dd.uniform((O,), 6, -0.5, 0.5)), T(dd.uniform((O,), 7, 0.5, 2.0))
+    v.update(ref.params_from_state(ast), whole, (mean, var, 1e-4))
+    # the same samples in the one-process ring: rank r's local row i is global row r * rows + i
+    idx = torch.cat([T(dd.integers((B // 2,), 8 + r, rows)) + r * rows for r in range(2)])
+    loss, grads = v.loss_and_grads(idx=idx, draw=T(dd.uniform((B, A), 9, -2, 2)))
+    full = torch.cat([g.reshape(-1) for g in grads]).numpy()
+    np.testing.assert_allclose(g0, full, rtol=1e-5, atol=1e-9)
+    assert abs(0.5 * (l0 + l1) - float(loss.detach())) <= 1e-6 * max(1.0, abs(float(loss.detach())))   # mean of rank means == global batch mean

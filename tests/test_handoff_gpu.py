@@ -374,3 +374,38 @@ def test_rollout_policy_forward_follows_every_way_its_weights_can_change():
     check(a, "in-place load before explore_env")
     with torch.no_grad():
         assert not torch.allclose(a(obs), b(obs))        # the policies do differ
+
+
+def test_published_snapshot_reads_wait_for_the_learner_stream():
+    """state_dict() / forward / the evaluator's spec of a PUBLISHED snapshot are enqueued on the caller's stream while the
+    snapshot is filled on the learner's: with the learner's queue stalled the reads must still see the published weights
+    (round-2 advisor finding: only deepcopy and adopt_arena honoured the lease)."""
+    from pql_amd.models.mlp import DoubleQ, TanhMLPPolicy
+    from pql_amd.utils import handoff as H
+    from pql_amd.utils.evaluator import module_to_spec
+    dev = torch.device("cuda:0")
+    for cls, args in ((DoubleQ, (8, 2)), (TanhMLPPolicy, (8, 2))):
+        live = cls(*args, hidden_layers=[64, 32]).to(dev)
+        pub = H.ArenaPublisher(live)
+        side = torch.cuda.Stream(dev)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            torch.cuda._sleep(400_000_000)          # ~0.2 s: the learner's queue is far behind the host
+            live.arena.data.fill_(0.25)             # "an optimiser step"
+            snap = pub.publish()
+        sd = snap.state_dict()                      # caller's (default) stream
+        spec = module_to_spec(snap)
+        x = torch.ones((4, 8), device=dev)
+        y = snap(x) if cls is TanhMLPPolicy else snap.get_q1(x, torch.ones((4, 2), device=dev))
+        with torch.cuda.stream(side):               # the publisher's next refill of that slot must wait for those reads
+            live.arena.data.fill_(-1.0)
+            pub.publish(); pub.publish()
+        torch.cuda.synchronize()
+        for k, t in sd.items():
+            assert torch.all(t == 0.25), k
+        for k, t in spec["state"].items():
+            assert torch.all(t == 0.25), k
+        ref = cls(*args, hidden_layers=[64, 32]).to(dev)
+        ref.arena.data.fill_(0.25)
+        want = ref(x) if cls is TanhMLPPolicy else ref.get_q1(x, torch.ones((4, 2), device=dev))
+        torch.testing.assert_close(y, want, rtol=0, atol=0)

@@ -342,6 +342,8 @@ def test_reference_cli_task_names_compose():
         env = create_task_env(cfg)
         assert (env.observation_space.shape[0], env.action_space.shape[0]) == shape
     assert load_cfg([]).algo.async_learners is False
+    with pytest.raises(ValueError, match="AlegroHand"):   # a typo fails at config load (Hydra: missing config), not later
+        load_cfg(["task=AlegroHand", "device=cpu"])
 
 
 # --------------------------------------------------------------------------- a25 ratio controller

@@ -287,6 +287,30 @@ def test_baseline_hidden_shape(golden, dev):
     np.testing.assert_allclose(x.grad.cpu().numpy(), g["mlp_h512_512_256_dx"], atol=2e-6)
 
 
+def test_reference_checkpoint_file_through_the_hip_mlp(golden, dev, tmp_path):
+    """f1: a checkpoint FILE in the reference's format (pql/utils/model_util.py:24-36) holding the weights of the reference's
+    own pql/model.pth (63 -> 512 -> 256 -> 128 -> 12 actor with its extra `logstd`, `critic.net.*` critic) goes through
+    `load_model` into the HIP MLPNet: outputs within 1e-5 and gradients within 2e-4 relative of the reference MLPNet's."""
+    from pql_amd.models.mlp import MLPNet
+    from pql_amd.utils.model_util import load_model
+    g = golden("ckpt")
+    actor_sd = {k[len("actor_w_"):]: T(g[k]) for k in g if k.startswith("actor_w_")}
+    actor_sd["logstd"] = T(g["actor_logstd"])                                       # unexpected key: ignored, like strict=False
+    critic_sd = {k[len("critic_w_"):]: T(g[k]) for k in g if k.startswith("critic_w_")}
+    path = str(tmp_path / "model.pth")
+    torch.save({"obs_rms": None, "actor": actor_sd, "critic": critic_sd}, path)
+    for role, out_dim in (("actor", 12), ("critic", 1)):
+        net = MLPNet(63, out_dim).to(dev)
+        assert load_model(net, role, path)
+        x = T(dd.uniform((19, 63), 7000 + out_dim, -2, 2)).to(dev).requires_grad_(True)
+        y = net(x)
+        (y * T(dd.uniform((19, out_dim), 7100 + out_dim)).to(dev)).sum().backward()
+        np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"{role}_y"], atol=1e-5)
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"{role}_dx"], atol=2e-6)
+        _check_grads(net, net.arena.grad, g, f"{role}_g_")
+    assert load_model(object(), "obs_rms", path) is False                          # the file carries no statistics
+
+
 @pytest.mark.parametrize("B", [8192, 777])
 def test_mlp_full_batch_vs_oracle(dev, ref, B):
     """BASELINE batch (8192) and a ragged batch: forward within 1e-5, gradients at 1e-4 relative of the

@@ -295,6 +295,38 @@ def test_fused_tail_matches_the_separate_launches(dev, distl):
     assert float(outs[0][4].abs().sum()) > 0 and float(outs[0][8].abs().sum()) > 0   # the folded losses did land in the rings
 
 
+def test_td_in_head_matches_the_separate_loss_launch(dev):
+    """algo.td_in_head: the scalar twin critic's TD target, MSE loss and dL/dQ are formed inside the head's backward pass
+    (k_skinny_bwd<1, CH, true>) instead of by pqlk_td_mse_loss + a dL/dQ round trip through memory.  Per sample the same
+    arithmetic in the same order, so the gradient -- and with it every parameter -- is BIT-equal; the loss value sums
+    its partials in different groups (64-row blocks per net instead of 256-row blocks) and agrees to 1e-6 relative."""
+    from pql_amd.algo.pql_v_learner import PQLVLearner
+    from pql_amd.models.mlp import TanhMLPPolicy
+    O, A, B, cap = 88, 16, 4096, 8000
+    actor = TanhMLPPolicy((O,), A, hidden_layers=[512, 512, 256]).to(dev)
+    actor.load_state_dict(_sd(dd.mlp_state(O, A, 63, (512, 512, 256))))
+    outs = []
+    for td in (True, False):
+        cfg = make_cfg(False, B=B, memory=cap, hidden=[512, 512, 256])
+        cfg.algo.td_in_head = td
+        v = PQLVLearner((O,), A, cfg)
+        v.critic.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 61, (512, 512, 256))))
+        v.critic_target.arena.data.copy_(v.critic.arena.data)
+        data = tuple(t.to(dev) for t in _fill(O, A, cap - 7, 377))
+        norm = (T(dd.uniform((O,), 831, -0.5, 0.5)).to(dev), T(dd.uniform((O,), 832, 0.5, 2.0)).to(dev), 1e-4)
+        v.update(actor, data, norm, 0)
+        for s in range(3):
+            v.learn(indices=T(dd.integers((B,), 940 + s, cap - 7)), noise=T(dd.uniform((B, A), 990 + s, -2, 2)))
+        torch.cuda.synchronize()
+        assert (v._ws["td_parts"] > 0) is td
+        outs.append((v.critic.arena.data.clone(), v.critic_target.arena.data.clone(), v.opt.m.clone(), v.opt.v.clone(), v.opt.gnorm.clone(),
+                     v._ws["grads"].clone(), v.loss_ring.clone()))
+    for a, b in zip(outs[0][:-1], outs[1][:-1]):
+        assert torch.equal(a, b)
+    torch.testing.assert_close(outs[0][-1], outs[1][-1], rtol=1e-6, atol=1e-9)
+    assert float(outs[0][-1].abs().sum()) > 0
+
+
 def test_graph_replay_matches_eager(dev):
     """hipGraph-captured learn() is the same launch sequence: with equal seeds it must reproduce the eager
     parameters bit for bit (same kernels, same order, same RNG offsets)."""
@@ -488,6 +520,79 @@ def test_evaluator_on_gpu_matches_plain_rollout(dev, tmp_path, subprocess_mode):
     assert load_model(a2, "actor", str(tmp_path / "model.pth")) and float(a2.arena.data.abs().sum()) > 0
     holder = RunningMeanStd(shape=(8,), device=dev)
     assert load_model(holder, "obs_rms", str(tmp_path / "model.pth")) and torch.allclose(holder.mean, rms.mean)
+
+
+def test_evaluator_against_the_oracle_composition(dev, tmp_path):
+    """f2 against the ORACLE, not against another HIP loop: the evaluation (pql/utils/evaluator.py:41-121 -- un-clamped
+    normalise -> actor -> env.step -> per-env return / length accumulators -> zero-filled windows of capacity
+    eval_num_envs -> their means) recomputed on the CPU from the env transitions the product saw (the env is an input of
+    both sides), with the oracle's actor forward and a deque.  Bars: every action within 1e-5 of the oracle's, result
+    means within 1e-6 relative, and the evaluated weights are those of the snapshot taken at eval_policy time."""
+    from collections import deque
+    from types import SimpleNamespace
+    from oracle import pql_ref_cpu as ref
+    from pql_amd.envs.synthetic import create_task_env
+    from pql_amd.models.mlp import DoubleQ, TanhMLPPolicy
+    from pql_amd.utils.cfg import load_cfg
+    from pql_amd.utils.evaluator import Evaluator
+    from pql_amd.utils.torch_util import RunningMeanStd
+    n, O, A = 150, 8, 2
+    cfg = load_cfg(["task.name=Toy", "task.episode_length=40", f"eval_num_envs={n}", "device=cuda:0", "eval_steps_per_poll=16"])
+    rec = {}
+
+    class Recording:
+        def __init__(self, env):
+            self.env, self.log, self.first_obs = env, [], None
+            self.observation_space, self.action_space = env.observation_space, env.action_space
+            self.max_episode_length, self.num_envs = env.max_episode_length, env.num_envs
+
+        def reset(self):
+            self.first_obs = self.env.reset().clone()
+            return self.first_obs
+
+        def step(self, action):
+            out = self.env.step(action)
+            self.log.append((action.clone(), out[0].clone(), out[1].clone(), out[2].clone()))
+            return out
+
+    def make_env(c, num_envs=None):
+        rec["env"] = Recording(create_task_env(c, num_envs=num_envs))
+        return rec["env"]
+
+    ast = dd.mlp_state(O, A, 17)
+    actor = TanhMLPPolicy((O,), A).to(dev)
+    actor.load_state_dict({k: T(v) for k, v in ast.items()})
+    critic = DoubleQ((O,), A).to(dev)
+    rms = RunningMeanStd(shape=(O,), device=dev)
+    rms.update(T(dd.uniform((512, O), 5, -3, 4)).to(dev))
+    ev = Evaluator(cfg, wandb_run=SimpleNamespace(dir=str(tmp_path)), create_task_env_func=make_env)
+    ev.eval_policy(actor, critic, step=7, normalizer=rms)
+    actor.arena.data.zero_()          # later training steps must not leak into the evaluation
+    polls = 0
+    while not ev.parent.poll():
+        polls += 1
+        assert polls < 100000
+    got = ev.parent.recv()
+    ev.close()
+    env = rec["env"]
+    assert len(env.log) == env.max_episode_length == 40
+    # ---- oracle composition on the recorded transitions
+    apar = ref.params_from_state(ast)
+    mean, var, eps = (t.cpu() if torch.is_tensor(t) else t for t in rms.get_states())
+    ret_win, len_win = deque([0.0] * n, maxlen=n), deque([0.0] * n, maxlen=n)     # Tracker(eval_num_envs): zero-filled
+    cur_ret, cur_len = torch.zeros(n), torch.zeros(n)
+    obs = env.first_obs.cpu()
+    for logged_act, nobs, rew, done in env.log:
+        act = ref.actor_forward_ref(apar, ref.normalize_ref(obs, (mean, var, eps), clamp=False))     # evaluator.py:66-68
+        torch.testing.assert_close(logged_act.cpu(), act, rtol=0, atol=1e-5)
+        cur_ret += rew.cpu(); cur_len += 1
+        fin = done.cpu().bool()
+        ret_win.extend(cur_ret[fin].tolist()); len_win.extend(cur_len[fin].tolist())
+        cur_ret[fin] = 0; cur_len[fin] = 0
+        obs = nobs.cpu()
+    assert sum(x != 0 for x in len_win) > 20                       # episodes did finish (mean length 40 over 40 steps x 150 envs)
+    assert got["eval/return"] == pytest.approx(float(np.mean(ret_win)), rel=1e-6, abs=1e-7)
+    assert got["eval/episode_length"] == pytest.approx(float(np.mean(len_win)), rel=1e-6)
 
 
 # --------------------------------------------------------------------------- SAC (SURVEY 8f rank 3)

@@ -167,6 +167,22 @@ def test_baseline_hidden_shape(golden):
     np.testing.assert_allclose(torch.autograd.grad(y.sum(), x)[0].numpy(), g["mlp_h512_512_256_dx"], atol=1e-6)
 
 
+def test_reference_checkpoint_weights_through_the_oracle(golden):
+    """f1: the reference's own pql/model.pth (weights stored as arrays in the fixture) through the oracle's MLP == the
+    reference MLPNet's outputs and gradients on it."""
+    g = golden("ckpt")
+    for role, out_dim in (("actor", 12), ("critic", 1)):
+        st = {k[len(role) + 3:]: g[k] for k in g if k.startswith(f"{role}_w_")}
+        params = [p.requires_grad_(True) for p in ref.params_from_state(st)]
+        x = T(dd.uniform((19, 63), 7000 + out_dim, -2, 2)).requires_grad_(True)
+        y = ref.mlp_forward_ref(params, x)
+        np.testing.assert_allclose(y.detach().numpy(), g[f"{role}_y"], atol=1e-6)
+        w = T(dd.uniform((19, out_dim), 7100 + out_dim))
+        gr = torch.autograd.grad((y * w).sum(), [x, *params])
+        np.testing.assert_allclose(gr[0].numpy(), g[f"{role}_dx"], atol=1e-6)
+        _grads_close(zip(_named(["net."], [params]), gr[1:]), g, f"{role}_g_")
+
+
 # --------------------------------------------------------------------------- math
 def test_projection(golden):
     g = golden("math")

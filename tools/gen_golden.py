@@ -560,13 +560,41 @@ def gen_crossq(R, out, steps=3):
     out["cq_norm_mean"] = norm[0]; out["cq_norm_var"] = norm[1]
 
 
+def gen_ckpt(R, out):
+    """f1: the ONE weight file the reference ships (pql/model.pth, a PPO actor / critic pair in the checkpoint format of
+    pql/utils/model_util.py:24-36) read with weights_only=True and pushed through the reference's MLPNet (mlp.py:27-40):
+    the weights themselves (data, 1.6 MB), outputs, input gradients and parameter-gradient fingerprints."""
+    ck = torch.load(os.path.join(REF, "pql", "model.pth"), map_location="cpu", weights_only=True)
+    assert ck["obs_rms"] is None
+    out["actor_logstd"] = ck["actor"]["logstd"].numpy()
+    for role, sd, strip in (("actor", ck["actor"], ""), ("critic", ck["critic"], "critic.")):
+        sd = {k[len(strip):]: v for k, v in sd.items() if k.startswith(strip + "net.")}
+        in_dim, out_dim = sd["net.0.weight"].shape[1], sd["net.6.weight"].shape[0]
+        net = R.MLPNet(in_dim, out_dim)     # default hidden [512, 256, 128] = the file's
+        net.load_state_dict(sd)
+        B = 19
+        x = T(dd.uniform((B, in_dim), 7000 + out_dim, -2, 2)).requires_grad_(True)
+        y = net(x)
+        w = T(dd.uniform((B, out_dim), 7100 + out_dim))
+        (y * w).sum().backward()
+        for k, v in sd.items():
+            out[f"{role}_w_{k}"] = v.numpy()
+        out[f"{role}_y"] = y.detach().numpy()
+        out[f"{role}_dx"] = x.grad.numpy()
+        for k, p in net.named_parameters():
+            out[f"{role}_g_{k}"] = dd.summarize(p.grad.numpy())
+
+
 def main():
     torch.set_num_threads(1)
     torch.manual_seed(0)
     R = _import_reference()
     os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])
     for name, fn in (("replay", gen_ring), ("nstep", gen_nstep), ("models", gen_models), ("math", gen_math),
-                     ("learners", gen_learners), ("sac", gen_sac), ("crossq", gen_crossq)):
+                     ("learners", gen_learners), ("sac", gen_sac), ("crossq", gen_crossq), ("ckpt", gen_ckpt)):
+        if only and name not in only:
+            continue
         out = {}
         with torch.no_grad() if name in ("replay", "nstep") else contextlib.nullcontext():
             fn(R, out)
