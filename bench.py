@@ -60,6 +60,9 @@ def parse():
                          "ends in such gaps: without this a 20-step timed region sits on that ramp.  Recorded in config.burn_in_ms; "
                          "0 disables")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--rng", default="auto", choices=["auto", "torch", "philox"],
+                    help="auto: the learners' draws of the next 8 (V) / 4 (P) steps from one libpqlk launch (torch's own numbers, verified on "
+                         "the device) + one batched replay gather; torch: randint + normal_ ATen launches and a gather per step (round 2)")
     ap.add_argument("--graph-rng", action="store_true", help="capture the learners' RNG draws inside their hipGraphs (A/B; default: in front)")
     ap.add_argument("--no-streams", action="store_true", help="serialise V / P / rollout on one stream")
     ap.add_argument("--no-fused", action="store_true", help="per-layer GEMM launches instead of the fused hidden-layer forward")
@@ -112,6 +115,7 @@ def build_system(args, rank, world, device, pg, learner_device=None):
     cfg = load_cfg(ov)
     cfg.algo.hidden_layers = hidden
     cfg.algo.fused_tail = not getattr(args, "no_fused_tail", False)
+    cfg.algo.rng = getattr(args, "rng", "auto")
     cfg.algo.reward_scale = 0.01   # preprocess_cfg's AllegroHand value (common.py:159-170)
     sh = getattr(args, "shard", None)
     env_offset = sh.env_offset if sh is not None else rank * args.num_envs
@@ -295,21 +299,30 @@ def dominant_kernel_ms(v, iters=20):
         return e0.elapsed_time(e1) / iters
 
 
-def gather_ms(v, iters=50):
-    """Device time of one fused replay gather launch (HIP events, same stream)."""
+def gather_ms(v, batches=1, iters=50):
+    """Device time of one fused replay gather launch of `batches` x B rows (HIP events, same stream): batches = 1 is the
+    per-step launch, batches = K the launch that serves the next K V-learner steps at once (PQLVLearner._prefetch)."""
     from pql_amd import _lib as L
     import ctypes as C
     ws = v._workspace(int(v.cfg.algo.batch_size))
     B = ws["B"]
+    rows = batches * B
     mean, var, eps = v._norm_ptrs()
-    idx = torch.randint(v.memory.cur_capacity, size=(iters + 3, B), device=v.device)
+    iters = max(4, min(iters, (1 << 24) // rows))
+    idx = torch.randint(v.memory.cur_capacity, size=(iters + 3, rows), device=v.device)
     fused_actor = v.pk_actor is not None and v.pk_actor.tensor is not None
+    f = dict(dtype=torch.float32, device=v.device)
+    if batches <= ws["K"]:
+        x_sa, xn_sa, rew, done = ws["x_sa_all"], ws["xn_sa_all"], ws["rew_all"], ws["done_all"]
+    else:
+        x_sa, xn_sa = torch.zeros((rows, ws["ld_sa"]), **f), torch.zeros((rows, ws["ld_sa"]), **f)
+        rew, done = torch.zeros(rows, **f), torch.zeros(rows, **f)
+    xn_obs = None if fused_actor else torch.zeros((rows, ws["ld_o"]), **f)
 
     def one(i):
-        L.check(L.lib.pqlk_replay_gather_fused(C.byref(v.memory.ring.desc), L.ptr(idx[i]), B, L.ptr(mean), L.ptr(var), eps, 3,
-                                               L.ptr(ws["x_sa"]), ws["ld_sa"], L.ptr(ws["xn_sa"]),
-                                               None if fused_actor else L.ptr(ws["xn_obs"]), ws["ld_o"],
-                                               L.ptr(ws["rew"]), L.ptr(ws["done"]), L.stream(v.device)))
+        L.check(L.lib.pqlk_replay_gather_fused(C.byref(v.memory.ring.desc), L.ptr(idx[i]), rows, L.ptr(mean), L.ptr(var), eps, 3,
+                                               L.ptr(x_sa), ws["ld_sa"], L.ptr(xn_sa), L.ptr(xn_obs), ws["ld_o"],
+                                               L.ptr(rew), L.ptr(done), L.stream(v.device)))
     with torch.cuda.device(v.device):
         for i in range(3):
             one(i)
@@ -606,7 +619,7 @@ def main():
                                f"{args.replay} rows resident in HBM, batch {args.batch}, n-step {args.nstep}, "
                                f"{'DistributionalDoubleQ(51)' if args.distl else 'DoubleQ'} MLP {hidden}",
                    "schedule": {"schedule": "1 env-iteration : 4 P-steps : 8 V-steps", "v_only": "v_only", "p_only": "p_only"}[mode],
-                   "graph": not args.no_graph, "burn_in_ms": args.burn_in_ms, "streams": not args.no_streams, "fused_forward": not args.no_fused,
+                   "graph": not args.no_graph, "rng": v.rng, "burn_in_ms": args.burn_in_ms, "streams": not args.no_streams, "fused_forward": not args.no_fused,
                    "parallelism": par, "layout": args.layout if args.gpus > 1 else "single", "ranks": world,
                    "per_rank": {"num_envs": args.num_envs, "replay_rows": args.replay, "batch": args.batch},
                    "job": {"num_envs": args.shard.total_envs, "replay_rows": args.replay * world, "batch": args.batch * world},
@@ -652,13 +665,20 @@ def main():
                 "kernel": "k_mlp_fwd_fused (twin-critic forward incl. the Q head, no stash): one launch",
                 "us_per_launch": dms * 1e3, "gflop_per_launch": f_dom / 1e9, "achieved": f_dom / (dms * 1e-3) / 1e12,
                 "frac": f_dom / (dms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
-        gms = gather_ms(v)
+        # the replay gather as the schedule launches it: one launch for the next K V-steps (K = 1 in the per-step torch-RNG mode)
+        K = int(v._workspace(args.batch)["K"])
+        gms = gather_ms(v, K)
         rec_ld = v.memory.ring.rec_ld
-        alg_bytes = args.batch * ((2 * O + A) * 4 + 4 + 1 + 8 + (2 * O + A) * 4 + 4 + 4)   # 1557 B/sample @cfg2
+        per_batch = args.batch * ((2 * O + A) * 4 + 4 + 1 + 8 + (2 * O + A) * 4 + 4 + 4)   # 1557 B/sample @cfg2
+        alg_bytes = K * per_batch
         line["roofline_gather"] = {"bound": "hbm", "kernel": "k_replay_gather_fused", "achieved": alg_bytes / (gms * 1e-3) / 1e9,
                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_bytes / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                   "traffic": traffic.get("gather_per_launch_bytes"), "algorithmic_bytes": alg_bytes,
-                                   "us_per_launch": gms * 1e3, "record_bytes": rec_ld * 4}
+                                   "traffic": traffic.get("gather_per_launch_bytes") if K == 1 else None, "algorithmic_bytes": alg_bytes,
+                                   "us_per_launch": gms * 1e3, "batches_per_launch": K, "rows_per_launch": K * args.batch,
+                                   "us_per_batch": gms * 1e3 / K, "record_bytes": rec_ld * 4}
+        if K > 1:   # the per-step launch (algo.rng=torch, injected draws) for comparison
+            g1 = gather_ms(v, 1)
+            line["roofline_gather"]["single_batch_launch"] = {"us_per_launch": g1 * 1e3, "frac": per_batch / (g1 * 1e-3) / 1e9 / PEAK_HBM_GBS}
         note("roofline sections measured")
         if world == 1 and mode == "schedule":
             line["free_running"] = free_running(actor, v, p, env, cfg, device)

@@ -233,6 +233,22 @@ int pqlk_mlp_backward_td(const PqlMlpDesc* d, const float* params, const float* 
                          float* sumsq_part, int32_t* step_dev, pqlk_stream_t stream);
 int32_t pqlk_td_head_loss_parts(const PqlMlpDesc* d, int64_t b);   /* 0: this layout cannot take pqlk_mlp_backward_td */
 
+/* The learners' random draws with torch's own numbers (csrc/philox.hip; reference draws: pql/replay/simple_replay.py:87,
+ * pql/utils/noise.py:20-21, pql/algo/pql_p_learner.py:49).  `chunks` consecutive learner steps in ONE launch: per step n_idx
+ * int64 indices uniform on [0, range) into idx[chunk][n_idx], then n_normal standard normals into normal[chunk][n_normal]
+ * (either part may be absent: n = 0 / NULL).  Chunk c holds exactly what
+ *     torch.randint(range, (n_idx,), generator=g);  torch.empty(n_normal).normal_(generator=g)
+ * return on a device generator g with this seed and Philox offset
+ *     base_offset + (step - base_step + c) * (pqlk_philox_increment(n_idx) + pqlk_philox_increment(n_normal)),
+ * step = step_dev[0] (a device step counter; NULL: base_step).  range < 2^28 (torch draws 64-bit values above).  contract:
+ * Box-Muller's affine map of the angle as one fma (how torch's build of rocRAND compiles it) or as mul + add; which one
+ * matches is checked against torch on the device by pql_amd/utils/rng.py, which falls back to ATen launches otherwise. */
+int pqlk_philox_draws(uint64_t seed, int64_t base_offset, int32_t base_step, const int32_t* step_dev, int64_t range,
+                      int64_t* idx, int64_t n_idx, float* normal, int64_t n_normal, int32_t chunks, int32_t contract,
+                      pqlk_stream_t stream);
+/* Philox offset increment of one torch draw of `numel` elements (4 values per counter block, at most 2048 x 256 threads). */
+int64_t pqlk_philox_increment(int64_t numel);
+
 /* Tuning hook of the replay gather (tools/bench_gather.py): rows in flight per wave (1, 2, 4, 8), resident waves per CU,
  * "skip the pad stores" and non-temporal record loads for the next launches (0 = automatic / off). */
 int pqlk_tune_gather(int rows_in_flight, int waves_per_cu, int nopad, int nt_loads);

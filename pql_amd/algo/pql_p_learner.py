@@ -25,6 +25,7 @@ from pql_amd.models import model_name_to_path
 from pql_amd.models.mlp import PackedWeights, default_splits, mlp_forward_raw, output_view
 from pql_amd.replay.simple_replay import RecordRing, _obs_width, ring_plan
 from pql_amd.utils import handoff as H
+from pql_amd.utils import rng as R
 from pql_amd.utils.common import Tracker, load_class_from_path
 
 
@@ -78,10 +79,16 @@ class PQLPLearner:
         self._capture_stream = torch.cuda.Stream(self.device)   # torch's default capture stream is shared by every graph
         self.gen = torch.Generator(device=self.device)   # own generator: see PQLVLearner.__init__
         self.gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
+        # algo.rng / algo.prefetch_steps: see PQLVLearner.__init__ (here: one randint per step, P-steps of one rollout iteration)
+        self._rng_mode = str(_cfg_get(algo, "rng", "auto"))
+        ratio = max(1, int(_cfg_get(algo, "critic_sample_ratio", 8)) // max(1, int(_cfg_get(algo, "critic_actor_ratio", 2))))
+        self._depth = max(1, int(_cfg_get(algo, "prefetch_steps_p", ratio)))
+        self._ahead = None
         self._ws = None
         self._graph = None
         self._graph_post = None
         self._graph_key = None
+        self._slot_graphs = {}
 
     @property
     def memory(self):
@@ -103,6 +110,23 @@ class PQLPLearner:
         """Re-seed this learner's generator."""
         self.gen.manual_seed(int(seed))
         self._graph = None
+        self._drop_ahead()
+
+    def _drop_ahead(self):
+        if self._ahead is not None:
+            self._ahead.invalidate()
+
+    @property
+    def rng(self):
+        return "philox" if self._ahead is not None else "torch"
+
+    def _want_ahead(self):
+        if self._rng_mode == "torch" or self._graph_rng:
+            return False
+        ok = R.verified(self.device) is not None
+        if not ok and self._rng_mode == "philox":
+            raise L.PqlkError("algo.rng=philox: pqlk_philox_draws does not reproduce torch.randint on this device; use auto / torch")
+        return ok
 
     def ready_to_learn(self):
         return self.critic is not None
@@ -122,8 +146,15 @@ class PQLPLearner:
         O, A = self.ring.O, self.action_dim
         al, cl = self.actor.layout, self.critic.layout
         ws = dict(B=B, ld_sa=L.ld(O + A), ld_o=L.ld(O), ld_a=L.ld(A))
-        ws["x_sa"] = torch.zeros((B, ws["ld_sa"]), **f)
-        ws["x_obs"] = torch.zeros((B, ws["ld_o"]), **f)
+        want = self._want_ahead()   # draws + gathered tiles of the next K steps (see PQLVLearner._workspace)
+        K = self._depth if want else 1
+        self._ahead = R.DrawAhead(self.gen, self.device, B, None, K, R.verified(self.device)) if want else None
+        self._slot_graphs = {}
+        ws["K"] = K
+        ws["x_sa_all"] = torch.zeros((K, B, ws["ld_sa"]), **f)
+        ws["x_obs_all"] = torch.zeros((K, B, ws["ld_o"]), **f)
+        ws["slots"] = [dict(x_sa=ws["x_sa_all"][k], x_obs=ws["x_obs_all"][k]) for k in range(K)]
+        ws.update(ws["slots"][0])
         ws["idx"] = torch.zeros(B, dtype=torch.int64, device=self.device)
         ws["acts_a"] = torch.empty(al.acts_floats(B), **f)
         ws["acts_c"] = torch.empty(cl.acts_floats(B), **f)
@@ -145,16 +176,27 @@ class PQLPLearner:
         if self.pk_critic is not None:
             self.pk_critic.refresh(self.critic.arena.data)
 
-    def _step_kernels(self, ws, idx, upto_backward=False):
+    def _gather(self, ws, idx, rows, x_sa, x_obs):
+        mean, var, eps = (None, None, 0.0)
+        if self.cfg.algo.obs_norm and self.normalize_tuple is not None:
+            mean, var, eps = self.normalize_tuple
+        L.check(L.lib.pqlk_replay_gather_fused(C.byref(self.ring.desc), L.ptr(idx), rows, L.ptr(mean), L.ptr(var), float(eps), GATHER_FLAGS,
+                                               L.ptr(x_sa), ws["ld_sa"], None, L.ptr(x_obs), ws["ld_o"], None, None,
+                                               L.stream(self.device)))
+
+    def _prefetch(self, ws):
+        """The next K steps' indices (torch's numbers, one launch) and ONE gather of their K x B observation rows."""
+        self._ahead.refill(self.cur_capacity)
+        self._gather(ws, self._ahead.idx, ws["K"] * ws["B"], ws["x_sa_all"], ws["x_obs_all"])
+
+    def _step_kernels(self, ws, idx, upto_backward=False, tiles=None):
         algo, dev, B = self.cfg.algo, self.device, ws["B"]
         O, A = self.ring.O, self.action_dim
         st = L.stream(dev)
-        mean, var, eps = (None, None, 0.0)
-        if algo.obs_norm and self.normalize_tuple is not None:
-            mean, var, eps = self.normalize_tuple
-        L.check(L.lib.pqlk_replay_gather_fused(C.byref(self.ring.desc), L.ptr(idx), B, L.ptr(mean), L.ptr(var), float(eps), GATHER_FLAGS,
-                                               L.ptr(ws["x_sa"]), ws["ld_sa"], None, L.ptr(ws["x_obs"]), ws["ld_o"], None, None,
-                                               st))
+        if tiles is None:   # per-step path: gather `idx` into slot 0 here
+            tiles = ws["slots"][0]
+            self._gather(ws, idx, B, tiles["x_sa"], tiles["x_obs"])
+        ws = dict(ws, **tiles)
         al, cl = self.actor.layout, self.critic.layout
         x_act = ws["x_sa"][:, O:]
         mlp_forward_raw(al, self.actor.arena.data, ws["x_obs"], L.ACT_TANH, acts=ws["acts_a"], out2=x_act, packed=self.pk_actor,
@@ -226,6 +268,23 @@ class PQLPLearner:
                 ws["idx"].copy_(indices.reshape(-1), non_blocking=indices.is_cuda)
                 H.release(lease, st)
                 self._step_kernels(ws, ws["idx"])
+            elif self._ahead is not None and self.cur_capacity < (1 << 28):   # see PQLVLearner.learn
+                if self._ahead.valid == 0:
+                    self._prefetch(ws)
+                slot = self._ahead.take()
+                if self.use_graph:
+                    key = (B, 0, id(self.critic), self.normalize_tuple is None)
+                    if self._graph_key != key:
+                        self._slot_graphs, self._graph, self._graph_post, self._graph_key = {}, None, None, key
+                    if slot not in self._slot_graphs:
+                        with H.CAPTURE_LOCK:
+                            self._capture(ws, key, slot)
+                    self._slot_graphs[slot].replay()
+                    if self._graph_post is not None:
+                        self._allreduce_grads(ws)
+                        self._graph_post.replay()
+                else:
+                    self._step_kernels(ws, None, tiles=ws["slots"][slot])
             elif self.use_graph:
                 key = (B, self.cur_capacity if self._graph_rng else 0, id(self.critic), self.normalize_tuple is None)
                 if self._graph is None or self._graph_key != key:
@@ -249,7 +308,19 @@ class PQLPLearner:
             return
         with self._lock, torch.cuda.device(self.device), self._on_stream():
             ws = self._workspace(int(self.cfg.algo.batch_size))
-            if self.use_graph:
+            if self.use_graph and self._ahead is not None and 0 < self.cur_capacity < (1 << 28):
+                key = (ws["B"], 0, id(self.critic), self.normalize_tuple is None)
+                if self._graph_key != key:
+                    self._slot_graphs, self._graph, self._graph_post, self._graph_key = {}, None, None, key
+                off = self.gen.get_offset()
+                self._prefetch(ws)              # real tiles for the captures' warm-up runs; nothing is consumed
+                for slot in range(ws["K"]):
+                    if slot not in self._slot_graphs:
+                        with H.CAPTURE_LOCK:
+                            self._capture(ws, key, slot)
+                self._drop_ahead()
+                self.gen.set_offset(off)
+            elif self.use_graph:
                 key = (ws["B"], self.cur_capacity if self._graph_rng else 0, id(self.critic), self.normalize_tuple is None)
                 if self._graph is None or self._graph_key != key:
                     with H.CAPTURE_LOCK:
@@ -273,13 +344,18 @@ class PQLPLearner:
         else:
             torch.cuda.set_rng_state(state, self.device)
 
-    def _capture(self, ws, key):
+    def _capture(self, ws, key, slot=None):
+        if slot is None:
+            step = lambda **kw: self._draw_and_step(ws, **kw)   # noqa: E731
+        else:   # the step reads the tiles `_prefetch` left in that slot: no RNG, no gather inside the graph
+            def step(upto_backward=False, draw=None):
+                self._step_kernels(ws, None, upto_backward, tiles=ws["slots"][slot])
         snap = [t.clone() for t in self._state()]
         rng = self._rng_state()
         s = torch.cuda.Stream(self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
-            self._draw_and_step(ws)
+            step()
         torch.cuda.current_stream(self.device).wait_stream(s)
         for dst, src in zip(self._state(), snap):
             dst.copy_(src)
@@ -290,15 +366,22 @@ class PQLPLearner:
         # ONE graph instead of splitting the step around an eager collective
         if not self.dp or graph_collective_enabled(self.pg):
             with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
-                self._draw_and_step(ws, draw=self._graph_rng)
+                step(draw=self._graph_rng)
         else:
             with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
-                self._draw_and_step(ws, upto_backward=True, draw=self._graph_rng)
-            g_post = self._new_graph()
-            with torch.cuda.graph(g_post, stream=self._capture_stream, capture_error_mode="thread_local"):
-                self._step_post(ws)
+                step(upto_backward=True, draw=self._graph_rng)
+            if slot is None or self._graph_post is None:   # (the optimiser graph is the same for every slot)
+                g_post = self._new_graph()
+                with torch.cuda.graph(g_post, stream=self._capture_stream, capture_error_mode="thread_local"):
+                    self._step_post(ws)
+            else:
+                g_post = self._graph_post
         self._set_rng_state(rng)
-        self._graph, self._graph_post, self._graph_key = g, g_post, key
+        if slot is None:
+            self._graph, self._graph_post, self._graph_key = g, g_post, key
+        else:
+            self._slot_graphs[slot] = g
+            self._graph_post, self._graph_key = g_post, key
 
     def loss_mean(self):
         """Exact mean of the last 5 losses (Tracker(5).mean(), zero-filled before 5 steps); synchronises."""
@@ -346,6 +429,7 @@ class PQLPLearner:
                                                                                obs.shape[0])
                 self.ring.insert_segments(segs, obs)
                 H.release(lease, st)
+            self._drop_ahead()   # ring contents, the randint bound and the statistics changed: later steps sample afresh
             loss = self._lagged.poll(self.update_count)
             return self._published(), loss, self.update_count
 

@@ -29,6 +29,7 @@ from pql_amd.models import model_name_to_path
 from pql_amd.models.mlp import PackedWeights, default_splits, mlp_forward_raw, output_view
 from pql_amd.replay.simple_replay import ReplayBuffer
 from pql_amd.utils import handoff as H
+from pql_amd.utils import rng as R
 from pql_amd.utils.common import Tracker, load_class_from_path
 
 LOSS_RING = 5  # Tracker(5) of the reference (:54)
@@ -277,10 +278,18 @@ class PQLVLearner:
         # default generator overwrite each other's offset (measured: different sample indices from run to run).
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))   # derived from the driver's seed (CPU generator)
+        # algo.rng: "auto" (default) = this library produces the draws itself, `algo.prefetch_steps` steps ahead in one launch,
+        # together with ONE batched replay gather for those steps -- if its numbers are torch's on this device
+        # (pql_amd/utils/rng.py), else "torch"; "torch" = one randint + one normal_ ATen launch in front of every step (round 2);
+        # "philox" = as auto, but refuse to run when the check fails.
+        self._rng_mode = str(_cfg_get(algo, "rng", "auto"))
+        self._depth = max(1, int(_cfg_get(algo, "prefetch_steps", _cfg_get(algo, "critic_sample_ratio", 8))))
+        self._ahead = None
         self._ws = None
         self._graph = None
         self._graph_post = None
         self._graph_key = None
+        self._slot_graphs = {}
 
     # ------------------------------------------------------------------------------------------
     def start(self):
@@ -298,6 +307,18 @@ class PQLVLearner:
         """Re-seed this learner's generator."""
         self.gen.manual_seed(int(seed))
         self._graph = None
+        self._drop_ahead()
+
+    def _drop_ahead(self):
+        """Forget the draws / gathered tiles prepared for later steps (the ring, its bound, the statistics or the generator
+        changed): the next step prepares them again at the generator's current offset."""
+        if self._ahead is not None:
+            self._ahead.invalidate()
+
+    @property
+    def rng(self):
+        """'philox' when the draws come from this library's launch, 'torch' when from ATen's (see __init__)."""
+        return "philox" if self._ahead is not None else "torch"
 
     def ready_to_learn(self):
         return self.actor is not None
@@ -318,11 +339,21 @@ class PQLVLearner:
         O, A = self.memory.ring.O, self.action_dim
         cl, al = self.critic.layout, self.actor.layout
         ws = dict(B=B, ld_sa=L.ld(O + A), ld_o=L.ld(O))
-        ws["x_sa"] = torch.zeros((B, ws["ld_sa"]), **f)
-        ws["xn_sa"] = torch.zeros((B, ws["ld_sa"]), **f)
+        # Draws and gathered input tiles of the next K steps (K = 1 without the fused draws): `x_sa` / `xn_sa` / `rew` / `done`
+        # are slot 0, the tiles of the per-step path.  cfg #2: K = 8 -> 2 x 33.5 MB of tiles.
+        want = self._want_ahead(B)
+        K = self._depth if want else 1
+        self._ahead = R.DrawAhead(self.gen, dev, B, (B, A), K, R.verified(dev)) if want else None
+        self._slot_graphs = {}
+        ws["K"] = K
+        ws["x_sa_all"] = torch.zeros((K, B, ws["ld_sa"]), **f)
+        ws["xn_sa_all"] = torch.zeros((K, B, ws["ld_sa"]), **f)
+        ws["rew_all"] = torch.zeros((K, B), **f)
+        ws["done_all"] = torch.zeros((K, B), **f)
+        ws["slots"] = [dict(x_sa=ws["x_sa_all"][k], xn_sa=ws["xn_sa_all"][k], rew=ws["rew_all"][k], done=ws["done_all"][k])
+                       for k in range(K)]
+        ws.update(ws["slots"][0])
         ws["xn_obs"] = torch.zeros((B, ws["ld_o"]), **f)
-        ws["rew"] = torch.zeros(B, **f)
-        ws["done"] = torch.zeros(B, **f)
         ws["idx"] = torch.zeros(B, dtype=torch.int64, device=dev)
         ws["draw"] = torch.zeros((B, A), **f)
         ws["acts_a"] = torch.empty(al.acts_floats(B), **f)
@@ -340,6 +371,17 @@ class PQLVLearner:
         self.repack()
         return ws
 
+    def _want_ahead(self, B):
+        """Fused draws + batched gather: needs the fused actor forward (it reads norm(next_obs) out of the target critic's input
+        tile, so a step's inputs are exactly two tiles), draws outside the graphs, and torch's numbers reproduced on this device."""
+        if self._rng_mode == "torch" or self._graph_rng or self.pk_actor is None or self.pk_actor.tensor is None:
+            return False
+        ok = R.verified(self.device) is not None
+        if not ok and self._rng_mode == "philox":
+            raise L.PqlkError("algo.rng=philox: pqlk_philox_draws does not reproduce torch.randint / normal_ on this device "
+                              "(another torch / rocRAND build?); use algo.rng=auto or torch")
+        return ok
+
     def repack(self):
         """Re-derive the fragment-ordered weight copies from the arenas (after loading a state_dict etc.)."""
         if self._fused:
@@ -354,20 +396,37 @@ class PQLVLearner:
         mean, var, eps = self.normalize_tuple
         return mean, var, float(eps)
 
-    def _step_kernels(self, ws, idx, draw, upto_backward=False):
-        """The launch sequence of one critic gradient step; everything asynchronous on the current stream.
-        upto_backward=True stops after the gradient is formed (graph capture around the DP all-reduce)."""
-        algo, dev, B = self.cfg.algo, self.device, ws["B"]
-        O = self.memory.ring.O
-        st = L.stream(dev)
+    def _gather(self, ws, idx, rows, x_sa, xn_sa, rew, done):
+        """Fused replay gather (+ normalise + concat) of `rows` samples into the given tiles."""
         mean, var, eps = self._norm_ptrs()
         # the fused actor forward masks everything past column O while staging its tile, so it can read norm(next_obs)
         # straight out of the target critic's input tile: one gather output (B x ld(O) floats) less to write
         actor_in_sa = self.pk_actor is not None and self.pk_actor.tensor is not None
-        L.check(L.lib.pqlk_replay_gather_fused(C.byref(self.memory.ring.desc), L.ptr(idx), B, L.ptr(mean), L.ptr(var), eps, GATHER_FLAGS,
-                                               L.ptr(ws["x_sa"]), ws["ld_sa"], L.ptr(ws["xn_sa"]),
-                                               None if actor_in_sa else L.ptr(ws["xn_obs"]),
-                                               ws["ld_o"], L.ptr(ws["rew"]), L.ptr(ws["done"]), st))
+        L.check(L.lib.pqlk_replay_gather_fused(C.byref(self.memory.ring.desc), L.ptr(idx), rows, L.ptr(mean), L.ptr(var), eps, GATHER_FLAGS,
+                                               L.ptr(x_sa), ws["ld_sa"], L.ptr(xn_sa), None if actor_in_sa else L.ptr(ws["xn_obs"]),
+                                               ws["ld_o"], L.ptr(rew), L.ptr(done), L.stream(self.device)))
+
+    def _prefetch(self, ws):
+        """Draws of the next K steps in one launch (torch's own numbers, pql_amd/utils/rng.py) and ONE gather of their K x B
+        rows: the ring does not change between two `update()` calls, so what the reference samples at the start of each of
+        those steps (simple_replay.py:85-104) can be fetched together -- 102 MB per launch at cfg #2 instead of eight
+        latency-bound 12.75-MB launches."""
+        K, B = ws["K"], ws["B"]
+        self._ahead.refill(self.memory.cur_capacity)
+        self._gather(ws, self._ahead.idx, K * B, ws["x_sa_all"], ws["xn_sa_all"], ws["rew_all"], ws["done_all"])
+
+    def _step_kernels(self, ws, idx, draw, upto_backward=False, tiles=None):
+        """The launch sequence of one critic gradient step; everything asynchronous on the current stream.
+        upto_backward=True stops after the gradient is formed (graph capture around the DP all-reduce).
+        tiles: input tiles already gathered by `_prefetch` (a slot of ws["slots"]); None = gather `idx` into slot 0 here."""
+        algo, dev, B = self.cfg.algo, self.device, ws["B"]
+        O = self.memory.ring.O
+        st = L.stream(dev)
+        actor_in_sa = self.pk_actor is not None and self.pk_actor.tensor is not None
+        if tiles is None:
+            tiles = ws["slots"][0]
+            self._gather(ws, idx, B, tiles["x_sa"], tiles["xn_sa"], tiles["rew"], tiles["done"])
+        ws = dict(ws, **tiles)   # the step below reads its inputs from `tiles`
         al, cl = self.actor.layout, self.critic.layout
         # target policy smoothing (:63-71): a' written into the action columns of the target critic's input.
         # The two no-grad chains (actor, target critic) skip the activation stash; the critic keeps it for backward.
@@ -470,6 +529,8 @@ class PQLVLearner:
         with self._lock, torch.cuda.device(self.device), self._on_stream():
             ws = self._workspace(B)
             if indices is not None or noise is not None:
+                if indices is None or noise is None:
+                    self._drop_ahead()   # the generator is about to be used directly: what was drawn ahead is off the stream now
                 if indices is not None:   # injected draws arrive on the caller's stream (or from the host)
                     self._inject(ws["idx"], indices, home)
                 else:
@@ -479,6 +540,25 @@ class PQLVLearner:
                 else:
                     ws["draw"].normal_(generator=self.gen)
                 self._step_kernels(ws, ws["idx"], ws["draw"])
+            elif self._ahead is not None and self.memory.cur_capacity < (1 << 28):
+                # draws + input tiles of the next K steps come from one launch pair (`_prefetch`), the step itself has no RNG
+                # and no gather launch left; one hipGraph per slot (the tiles' addresses are baked in)
+                if self._ahead.valid == 0:
+                    self._prefetch(ws)
+                slot = self._ahead.take()
+                if self.use_graph:
+                    key = (B, 0, id(self.actor), self.normalize_tuple is None)
+                    if self._graph_key != key:
+                        self._slot_graphs, self._graph, self._graph_post, self._graph_key = {}, None, None, key
+                    if slot not in self._slot_graphs:
+                        with H.CAPTURE_LOCK:
+                            self._capture(ws, key, slot)
+                    self._slot_graphs[slot].replay()
+                    if self._graph_post is not None:   # data parallel: the collective stays outside the graphs
+                        self._allreduce_grads(ws)
+                        self._graph_post.replay()
+                else:
+                    self._step_kernels(ws, None, self._ahead.normal[slot], tiles=ws["slots"][slot])
             elif self.use_graph:
                 key = (B, self.memory.cur_capacity if self._graph_rng else 0, id(self.actor), self.normalize_tuple is None)
                 if self._graph is None or self._graph_key != key:
@@ -503,7 +583,19 @@ class PQLVLearner:
             return
         with self._lock, torch.cuda.device(self.device), self._on_stream():
             ws = self._workspace(int(self.cfg.algo.batch_size))
-            if self.use_graph:
+            if self.use_graph and self._ahead is not None and 0 < self.memory.cur_capacity < (1 << 28):
+                key = (ws["B"], 0, id(self.actor), self.normalize_tuple is None)
+                if self._graph_key != key:
+                    self._slot_graphs, self._graph, self._graph_post, self._graph_key = {}, None, None, key
+                off = self.gen.get_offset()
+                self._prefetch(ws)              # (the captures' warm-up runs need real tiles; nothing is consumed: the
+                for slot in range(ws["K"]):     #  generator is put back and the tiles are dropped)
+                    if slot not in self._slot_graphs:
+                        with H.CAPTURE_LOCK:
+                            self._capture(ws, key, slot)
+                self._drop_ahead()
+                self.gen.set_offset(off)
+            elif self.use_graph:
                 key = (ws["B"], self.memory.cur_capacity if self._graph_rng else 0, id(self.actor), self.normalize_tuple is None)
                 if self._graph is None or self._graph_key != key:
                     with H.CAPTURE_LOCK:
@@ -515,15 +607,21 @@ class PQLVLearner:
         dst.copy_(src.reshape(dst.shape), non_blocking=src.is_cuda)
         H.release(lease, st)
 
-    def _capture(self, ws, key):
+    def _capture(self, ws, key, slot=None):
         """Capture the whole step into a hipGraph.  With `algo.graph_rng` the RNG draws are captured too; the graph then bakes
-        in cur_capacity (the randint bound) and is re-captured while the ring is still filling."""
+        in cur_capacity (the randint bound) and is re-captured while the ring is still filling.  slot: the step reads the
+        draws / tiles `_prefetch` left in that slot (no RNG, no gather inside the graph); one graph per slot."""
+        if slot is None:
+            step = lambda **kw: self._draw_and_step(ws, **kw)   # noqa: E731
+        else:
+            def step(upto_backward=False, draw=None):
+                self._step_kernels(ws, None, self._ahead.normal[slot], upto_backward, tiles=ws["slots"][slot])
         # warm-up outside capture (lazy hipFuncSetAttribute / allocator state), on a side stream as torch requires
         snap = self._snapshot()
         s = torch.cuda.Stream(self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
-            self._draw_and_step(ws)
+            step()
         torch.cuda.current_stream(self.device).wait_stream(s)
         self._restore(snap)
         g, g_post = self._new_graph(), None
@@ -531,15 +629,22 @@ class PQLVLearner:
         # ONE graph instead of splitting the step around an eager collective
         if not self.dp or graph_collective_enabled(self.pg):
             with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
-                self._draw_and_step(ws, draw=self._graph_rng)
+                step(draw=self._graph_rng)
         else:   # two graphs around the RCCL all-reduce (kept eager: no collective is ever captured)
             with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
-                self._draw_and_step(ws, upto_backward=True, draw=self._graph_rng)
-            g_post = self._new_graph()
-            with torch.cuda.graph(g_post, stream=self._capture_stream, capture_error_mode="thread_local"):
-                self._step_post(ws)
+                step(upto_backward=True, draw=self._graph_rng)
+            if slot is None or self._graph_post is None:   # (the optimiser graph is the same for every slot)
+                g_post = self._new_graph()
+                with torch.cuda.graph(g_post, stream=self._capture_stream, capture_error_mode="thread_local"):
+                    self._step_post(ws)
+            else:
+                g_post = self._graph_post
         self._restore(snap)  # capture does not execute, but keep state exactly as before
-        self._graph, self._graph_post, self._graph_key = g, g_post, key
+        if slot is None:
+            self._graph, self._graph_post, self._graph_key = g, g_post, key
+        else:
+            self._slot_graphs[slot] = g
+            self._graph_post, self._graph_key = g_post, key
 
     def _new_graph(self):
         g = torch.cuda.CUDAGraph()
@@ -605,6 +710,7 @@ class PQLVLearner:
                 self.memory.add_to_buffer(trajectory)
                 H.release(lease, st)
             self.normalize_tuple = resident_norm(self, normalize_tuple, home)
+            self._drop_ahead()   # ring contents, the randint bound and the statistics changed: later steps sample afresh
             loss = self._lagged.poll(self.update_count)
             self.sleep_time = sleep_time
             return self._published(), loss, self.update_count

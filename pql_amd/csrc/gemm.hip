@@ -816,7 +816,10 @@ static int launch_gemm(GemmP p, int gz, hipStream_t st) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dshmem);
         if (e != hipSuccess) return -(int)e;
       }
-      p.frag_ahead = (g_pqlk_knob[1] >> (MODE == MODE_DW ? 0 : 1)) & 1;   // knob 1: bit 0 = dW products, bit 1 = dX products
+      // dX products only (k-contiguous dY fragments: four ds_read_b128 + sixteen ds_read_b32 per stage): backward of the twin
+      // critic 270.3 -> 262.9 us; the dW products (both operands reduction-row: 32 ds_read2st64_b32 per stage) ran 2 % SLOWER
+      // with it (tools/kbench.py, interleaved rounds on one box, round 3)
+      p.frag_ahead = (MODE == MODE_DX && !g_pqlk_knob[1]) ? 1 : 0;
       hipLaunchKernelGGL((k_gemm<MODE, BM, BN, EPI, KT, true>), grid, dim3(256), dshmem, st, p);
       PQLK_LAUNCH_CHECK();
       return PQLK_OK;

@@ -327,6 +327,45 @@ def test_td_in_head_matches_the_separate_loss_launch(dev):
     assert float(outs[0][-1].abs().sum()) > 0
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_draws_ahead_and_batched_gather_equal_the_per_step_torch_draws(dev, graph):
+    """algo.rng=auto: the draws of the next K steps come from one pqlk_philox_draws launch and their K x B rows from one gather,
+    instead of randint + normal_ + gather per step (algo.rng=torch, the reference's call pattern).  Same seeds
+    -> the SAME indices and noise, hence bit-identical parameters, optimiser state and loss rings for both learners -- across
+    `update()` calls that arrive in the middle of a prefetched run (3 steps, update, 8 steps, update, 5 steps: the leftovers are
+    dropped and re-drawn at the generator's offset) and with the step replayed from per-slot hipGraphs."""
+    from pql_amd.algo.pql_p_learner import PQLPLearner
+    from pql_amd.algo.pql_v_learner import PQLVLearner
+    O, A, B, cap = 8, 2, 256, 3000
+    outs = []
+    for mode in ("torch", "auto"):
+        cfg = make_cfg(False, B=B, memory=cap, graph=graph)
+        cfg.algo.rng = mode
+        v, p = PQLVLearner((O,), A, cfg), PQLPLearner((O,), A, cfg)
+        assert v._depth == 8 and p._depth == 4
+        v.critic.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 21))); v.critic_target.arena.data.copy_(v.critic.arena.data)
+        p.actor.load_state_dict(_sd(dd.mlp_state(O, A, 11)))
+        v.use_private_rng(1234); p.use_private_rng(4321)
+        norm = (T(dd.uniform((O,), 6, -0.5, 0.5)).to(dev), T(dd.uniform((O,), 7, 0.5, 2.0)).to(dev), 1e-4)
+        idxs = []
+        for phase, steps in enumerate((3, 8, 5)):
+            data = tuple(t.to(dev) for t in _fill(O, A, 700, 50 + 10 * phase))      # the ring grows: the randint bound changes
+            critic, _, _ = v.update(p.actor, data, norm, 0)
+            p.update(critic, data[0], norm, 0)
+            for k in range(steps):
+                v.learn()
+                if k % 2 == 1:
+                    p.learn()
+                idxs.append(v._ahead.idx[(v._ahead.pos - 1)].clone() if v._ahead is not None else v._ws["idx"].clone())
+        torch.cuda.synchronize()
+        assert v.rng == ("philox" if mode == "auto" else "torch") == p.rng
+        outs.append((v.critic.arena.data.clone(), v.critic_target.arena.data.clone(), v.opt.m.clone(), v.opt.v.clone(), v.loss_ring.clone(),
+                     p.actor.arena.data.clone(), p.opt.m.clone(), p.loss_ring.clone(), torch.stack(idxs), v.gen.get_offset(), p.gen.get_offset()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+    assert v.update_count == 16 and p.update_count == 8
+
+
 def test_graph_replay_matches_eager(dev):
     """hipGraph-captured learn() is the same launch sequence: with equal seeds it must reproduce the eager
     parameters bit for bit (same kernels, same order, same RNG offsets)."""

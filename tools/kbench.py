@@ -81,7 +81,9 @@ def main():
                     L.lib.pqlk_debug_knob(int(k), int(val))
         v._ws = None
         v._graph = None
+        p._ws = None
         p._graph = None
+        p._workspace(B)
         return v._workspace(B)
 
     def sec_actor():
