@@ -183,10 +183,10 @@ struct Smem {
 // magnitude inside the 1e-5 parity bar, and ~6 us cheaper per 8192x512x2 epilogue than libm's expm1f.
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
-template <int MODE, int BM, int BN, int EPI, int KT, bool DMA = false>
-// exactly 2 waves per SIMD (3 for the 128 x 64 tile): the register allocator otherwise aims for 4 and spills the second tile set
-#define PQLK_GEMM_WPE (BM == 128 && BN == 64 ? 3 : 2)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_WPE, PQLK_GEMM_WPE))) void k_gemm(GemmP p) {
+// One output tile of one product.  (bx, by, bz) = the block's place in a (gx, gy, .) grid of tiles: k_gemm passes blockIdx /
+// gridDim, k_gemm_pair the coordinates inside its sub-grid.
+template <int MODE, int BM, int BN, int EPI, int KT, bool DMA>
+__device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz, const int gx, const int gy) {
   constexpr int WM = BM / 2, WN = BN / 2;  // per-wave patch
   constexpr int MI = WM / 32, NJ = WN / 32;
   constexpr int KC_LD = KT + 4;
@@ -207,9 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
   // operand -- the column tiles of one row tile (dX / forward: the same rows of A), all tiles of one (net, batch split) of a dW
   // product (the same rows of dY and X) -- would sit under 8 different L2s and each fetch the operand across the fabric.
   // Re-label: dispatch slot w lands on XCD w % 8; give that XCD whole groups of G sharing tiles, G consecutive slots each.
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (p.xcd_remap) {
-    const int gx = gridDim.x, gy = gridDim.y;
     const int G = (MODE == MODE_DW) ? gx * gy : gx;
     const int w = bx + gx * (by + gy * bz), sl = w >> 3;
     const int L = ((sl / G) * 8 + (w & 7)) * G + sl % G;
@@ -765,6 +763,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_W
     }
 }
 
+template <int MODE, int BM, int BN, int EPI, int KT, bool DMA = false>
+// exactly 2 waves per SIMD (3 for the 128 x 64 tile): the register allocator otherwise aims for 4 and spills the second tile set
+#define PQLK_GEMM_WPE (BM == 128 && BN == 64 ? 3 : 2)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PQLK_GEMM_WPE, PQLK_GEMM_WPE))) void k_gemm(GemmP p) {
+  gemm_body<MODE, BM, BN, EPI, KT, DMA>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y);
+}
+
+// dW_l and dX_l of one layer in ONE launch (both read dZ_l; neither reads the other's output: mlp.py's autograd computes them
+// from the same upstream gradient).  Blocks [0, nw) are the dW product's tiles, the rest the dX product's (LDS-DMA loops, dX with
+// the ELU' epilogue).  Why: each product alone is one wave of identical blocks that start together, run the same k loop and
+// reach their epilogues together -- prologue and epilogue overlap nothing -- and at n_nets = 1 (the actor) or 256-column layers a
+// product has only one block per CU.  Here a CU hosts blocks of two different programs with different lengths, so one block's
+// epilogue / prologue runs under the other's MFMA stream, and the second product's blocks start as the first's finish
+// instead of behind a launch boundary.  Per-block arithmetic unchanged: same bits as two launches.
+template <int BW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm_pair(GemmP pw, GemmP px, int nw, int gxw, int gyw,
+                                                                                               int gxx, int gyx) {
+  int b = blockIdx.x;
+  if (b < nw) {   // block-uniform
+    gemm_body<MODE_DW, BW, BW, EPI_NONE, 16, true>(pw, b % gxw, (b / gxw) % gyw, b / (gxw * gyw), gxw, gyw);
+  } else {
+    b -= nw;
+    gemm_body<MODE_DX, 128, 128, EPI_DELU, 16, true>(px, b % gxx, (b / gxx) % gyx, b / (gxx * gyx), gxx, gyx);
+  }
+}
+
 // PQLK_GEMM_DMA=0 keeps every GEMM on the register-staged main loop (A/B switch of the LDS-DMA loop; read once)
 static bool gemm_dma_enabled() {
   static const bool on = [] { const char* e = getenv("PQLK_GEMM_DMA"); return !(e && e[0] == '0'); }();
@@ -774,6 +798,44 @@ static bool gemm_dma_enabled() {
 static bool gemm_xcd_enabled() {   // PQLK_GEMM_XCD=0: dispatch-order tiles (A/B switch of the XCD-aware order; read once)
   static const bool on = [] { const char* e = getenv("PQLK_GEMM_XCD"); return !(e && e[0] == '0'); }();
   return on;
+}
+
+// grid, XCD re-labelling and main-loop choice of one product; returns true when the LDS-DMA loop applies (every tile of the
+// grid interior, whole 16-deep stages in multiples of four, 16-B aligned operands)
+template <int MODE, int BM, int BN, int EPI>
+static bool gemm_plan(GemmP& p, int gz, dim3& grid) {
+  constexpr int KT = PQLK_KT;
+  int ncols = (MODE == MODE_DW) ? p.N : p.ncols_store;
+  p.n_base = 0;
+  if (MODE == MODE_DX && EPI == EPI_DTANH_SLICE) {  // only the action columns are wanted
+    p.n_base = p.col0 & ~3;
+    ncols = p.col0 + p.ncol - p.n_base;
+  }
+  grid = dim3((unsigned)((ncols + BN - 1) / BN), (unsigned)((p.M + BM - 1) / BM), (unsigned)gz);
+  {
+    const long long tiles = (long long)grid.x * grid.y * grid.z, group = (MODE == MODE_DW) ? (long long)grid.x * grid.y : grid.x;
+    p.xcd_remap = gemm_xcd_enabled() && tiles % (8 * group) == 0 && tiles < (1LL << 30);
+  }
+  p.frag_ahead = 0;
+  if constexpr (KT == 16 && (MODE == MODE_DX || MODE == MODE_DW) && (EPI == EPI_DELU || EPI == EPI_NONE)) {
+    bool dma = gemm_dma_enabled() && p.M % BM == 0 && ncols % BN == 0 && p.N % BN == 0 && !p.C2 && pqlk_aligned16(p.A) &&
+               pqlk_aligned16(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0 && (EPI != EPI_DELU || (p.aux && pqlk_aligned16(p.aux) && p.ldaux % 4 == 0));
+    if (MODE == MODE_DX) dma = dma && p.K % (4 * KT) == 0 && p.K <= p.lda && ncols <= p.ldb && p.sA % 4 == 0 && p.sB % 4 == 0;
+    else dma = dma && p.rows_per_split % (4 * KT) == 0 && p.K % p.rows_per_split == 0 && p.K / p.rows_per_split == p.splits &&
+               p.M <= p.lda && p.N <= p.ldb && p.sA % 4 == 0 && p.sB % 4 == 0;
+    // fragments a stage ahead: dX products only (k-contiguous dY fragments: four ds_read_b128 + sixteen ds_read_b32 per stage):
+    // backward of the twin critic 270.3 -> 262.9 us; the dW products (both operands reduction-row: 32 ds_read2st64_b32 per
+    // stage) ran 2 % SLOWER with it (tools/kbench.py, interleaved rounds on one box, round 3)
+    if (dma) p.frag_ahead = (MODE == MODE_DX && !g_pqlk_knob[1]) ? 1 : 0;
+    return dma;
+  }
+  return false;
+}
+
+template <int BM, int BN, int KT>
+static constexpr size_t gemm_dma_lds() {
+  constexpr size_t dma_floats = (size_t)4 * (BM + BN) * KT, patch_floats = (size_t)4 * 32 * (BN / 2 + 4);
+  return (dma_floats > patch_floats ? dma_floats : patch_floats) * sizeof(float);
 }
 
 template <int MODE, int BM, int BN, int EPI>
@@ -789,37 +851,17 @@ static int launch_gemm(GemmP p, int gz, hipStream_t st) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     if (e != hipSuccess) return -(int)e;
   }
-  int ncols = (MODE == MODE_DW) ? p.N : p.ncols_store;
-  p.n_base = 0;
-  if (MODE == MODE_DX && EPI == EPI_DTANH_SLICE) {  // only the action columns are wanted
-    p.n_base = p.col0 & ~3;
-    ncols = p.col0 + p.ncol - p.n_base;
-  }
-  dim3 grid((unsigned)((ncols + BN - 1) / BN), (unsigned)((p.M + BM - 1) / BM), (unsigned)gz);
-  {
-    const long long tiles = (long long)grid.x * grid.y * grid.z, group = (MODE == MODE_DW) ? (long long)grid.x * grid.y : grid.x;
-    p.xcd_remap = gemm_xcd_enabled() && tiles % (8 * group) == 0 && tiles < (1LL << 30);
-  }
+  dim3 grid;
+  const bool dma = gemm_plan<MODE, BM, BN, EPI>(p, gz, grid);
   if constexpr (KT == 16 && (MODE == MODE_DX || MODE == MODE_DW) && (EPI == EPI_DELU || EPI == EPI_NONE)) {
-    // LDS-DMA main loop: every tile of the grid interior, whole 16-deep stages in multiples of four, 16-B aligned operands
-    bool dma = gemm_dma_enabled() && p.M % BM == 0 && ncols % BN == 0 && p.N % BN == 0 && !p.C2 && pqlk_aligned16(p.A) &&
-               pqlk_aligned16(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0 && (EPI != EPI_DELU || (p.aux && pqlk_aligned16(p.aux) && p.ldaux % 4 == 0));
-    if (MODE == MODE_DX) dma = dma && p.K % (4 * KT) == 0 && p.K <= p.lda && ncols <= p.ldb && p.sA % 4 == 0 && p.sB % 4 == 0;
-    else dma = dma && p.rows_per_split % (4 * KT) == 0 && p.K % p.rows_per_split == 0 && p.K / p.rows_per_split == p.splits &&
-               p.M <= p.lda && p.N <= p.ldb && p.sA % 4 == 0 && p.sB % 4 == 0;
     if (dma) {
-      constexpr size_t dma_floats = (size_t)4 * (BM + BN) * KT;
-      const size_t dshmem = (dma_floats > patch_floats ? dma_floats : patch_floats) * sizeof(float);
+      constexpr size_t dshmem = gemm_dma_lds<BM, BN, KT>();
       static PqlkPerDeviceOnce dma_once;
       if (dma_once.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, BM, BN, EPI, KT, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)dshmem);
         if (e != hipSuccess) return -(int)e;
       }
-      // dX products only (k-contiguous dY fragments: four ds_read_b128 + sixteen ds_read_b32 per stage): backward of the twin
-      // critic 270.3 -> 262.9 us; the dW products (both operands reduction-row: 32 ds_read2st64_b32 per stage) ran 2 % SLOWER
-      // with it (tools/kbench.py, interleaved rounds on one box, round 3)
-      p.frag_ahead = (MODE == MODE_DX && !g_pqlk_knob[1]) ? 1 : 0;
       hipLaunchKernelGGL((k_gemm<MODE, BM, BN, EPI, KT, true>), grid, dim3(256), dshmem, st, p);
       PQLK_LAUNCH_CHECK();
       return PQLK_OK;
@@ -828,6 +870,36 @@ static int launch_gemm(GemmP p, int gz, hipStream_t st) {
   hipLaunchKernelGGL((k_gemm<MODE, BM, BN, EPI, KT>), grid, dim3(256), shmem, st, p);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
+}
+
+// dW_l + dX_l of one hidden layer in one launch (k_gemm_pair).  PQLK_E_UNSUPPORTED when either product cannot take the LDS-DMA
+// loop at the tile the stand-alone launcher would pick (the caller then launches them one after the other).
+template <int BW>
+static int launch_pair_t(GemmP pw, int gzw, GemmP px, int gzx, hipStream_t st) {
+  dim3 gw, gx;
+  if (!gemm_plan<MODE_DW, BW, BW, EPI_NONE>(pw, gzw, gw) || !gemm_plan<MODE_DX, 128, 128, EPI_DELU>(px, gzx, gx)) return PQLK_E_UNSUPPORTED;
+  const long long nw = (long long)gw.x * gw.y * gw.z, nx = (long long)gx.x * gx.y * gx.z;
+  if (nw % 8 != 0 || nw + nx >= (1LL << 30)) return PQLK_E_UNSUPPORTED;   // (the dX tiles' XCD classes are those of their dispatch slots)
+  constexpr size_t lw = gemm_dma_lds<BW, BW, PQLK_KT>(), lx = gemm_dma_lds<128, 128, PQLK_KT>(), lds = lw > lx ? lw : lx;
+  static PqlkPerDeviceOnce once;
+  if (once.need()) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pair<BW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return -(int)e;
+  }
+  hipLaunchKernelGGL((k_gemm_pair<BW>), dim3((unsigned)(nw + nx)), dim3(256), lds, st, pw, px, (int)nw, (int)gw.x, (int)gw.y, (int)gx.x,
+                     (int)gx.y);
+  PQLK_LAUNCH_CHECK();
+  return PQLK_OK;
+}
+
+static int launch_pair(const GemmP& pw, int gzw, const GemmP& px, int gzx, hipStream_t st) {
+  if (PQLK_KT != 16 || g_pqlk_knob[2]) return PQLK_E_UNSUPPORTED;
+  // the tiles the stand-alone launchers would pick (launch_tile): dX must be on 128 x 128, dW on 128 x 128 or 64 x 64
+  const long long big_x = (long long)((px.M + 127) / 128) * ((px.ncols_store + 127) / 128) * gzx;
+  if (big_x < 256 || px.ncols_store < 128) return PQLK_E_UNSUPPORTED;
+  const long long big_w = (long long)((pw.M + 127) / 128) * ((pw.N + 127) / 128) * gzw;
+  if (big_w >= 256 && pw.N >= 128) return launch_pair_t<128>(pw, gzw, px, gzx, st);
+  return launch_pair_t<64>(pw, gzw, px, gzx, st);
 }
 
 // Pick the tile: 128x128 when that already gives every CU a block, else 64x64.
@@ -1361,6 +1433,36 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
       }
       if (!dx) continue;
     }
+    bool paired = false;
+    if (grads && !skinny && l > 0) {   // dW_l (+ db_l) and dX_l read the same dZ_l and nothing of each other: one launch
+      GemmP pw = {}, px = {};
+      pw.A = cur_dy; pw.lda = (int)ld_out; pw.sA = b * ld_out;
+      pw.B = in; pw.ldb = (int)in_ld; pw.sB = in_stride;
+      pw.C = slabs + w_off; pw.ldc = (int)ld_in; pw.sC = net_stride;
+      pw.dbias = slabs + b_off; pw.sBias = net_stride;
+      pw.M = d->dims[l + 1]; pw.N = (int)ld_in; pw.K = (int)b;
+      pw.ncols_store = (int)ld_out;
+      pw.groups = d->n_nets; pw.splits = splits;
+      pw.rows_per_split = (int)pqlk_round_up((b + splits - 1) / splits, KT_MAX);
+      pw.sSplit = arena;
+      px.A = cur_dy; px.lda = (int)ld_out; px.sA = b * ld_out;
+      px.B = params + w_off; px.ldb = (int)ld_in; px.sB = net_stride;
+      px.C = dact[flip]; px.ldc = (int)ld_in; px.sC = b * ld_in;
+      px.aux = in; px.ldaux = (int)in_ld; px.sAux = in_stride;
+      px.M = (int)b; px.N = d->dims[l]; px.K = d->dims[l + 1];
+      px.ncols_store = (int)ld_in;
+      px.groups = d->n_nets; px.zsum = 0;
+      px.epi = EPI_DELU;
+      rc = launch_pair(pw, d->n_nets * splits, px, d->n_nets, st);
+      if (rc == PQLK_OK) {
+        paired = true;
+        cur_dy = dact[flip];
+        flip ^= 1;
+      } else if (rc != PQLK_E_UNSUPPORTED) {
+        return rc;
+      }
+    }
+    if (paired) continue;
     if (grads && !skinny) {  // dW_l, db_l
       GemmP p = {};
       p.A = cur_dy; p.lda = (int)ld_out; p.sA = b * ld_out;
