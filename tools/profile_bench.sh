@@ -14,7 +14,9 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 run() {   # name, bench flags...
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python3 bench.py --no-cpu-baseline --repeat 1 "$@" \
+  # (--burn-in-ms 0 --no-roofline: nothing but set-up, warm-up and the timed steps launches kernels, so the CSV's call counts are
+  #  (steps + warm-up) x launches per step plus the set-up's -- tests/test_profiles_cpu.py checks that)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -o $name -- python3 bench.py --no-cpu-baseline --repeat 1 --burn-in-ms 0 --no-roofline "$@" \
       > $OUT/${name}_under_rocprof.json 2> $OUT/${name}.err || { tail -5 $OUT/${name}.err; return 1; }
   f=$(find $OUT/$name -name "*kernel_stats.csv" | head -1)
   cp "$f" $OUT/${name}_kernel_stats.csv
