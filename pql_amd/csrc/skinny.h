@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256) void k_skinny_bwd(SkinnyP p, float* __restrict
   for (int j0 = 0; j0 < rows_per_block / 4; j0 += RIF) {
     float4 xv[RIF][CH];
     float dyl[RIF];
+    float tdq[TD ? RIF : 1], tdr[TD ? RIF : 1], tdd[TD ? RIF : 1], tdt[TD ? RIF : 1];
 #pragma unroll
     for (int u = 0; u < RIF; ++u) {
       const int m = m_blk + wave + 4 * (j0 + u);
@@ -328,17 +329,23 @@ __global__ __launch_bounds__(256) void k_skinny_bwd(SkinnyP p, float* __restrict
         const int q = lane + 64 * c;
         xv[u][c] = (ok && q < kq) ? *reinterpret_cast<const float4*>(X + (long long)m * p.ldx + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if constexpr (TD) {   // wave-uniform addresses: one request each
-        float dq = 0.f;
-        if (ok) {
-          const float t1 = p.td_qt[(long long)m * p.ldy], t2 = p.td_qt[((long long)p.M + m) * p.ldy];
-          const float y = p.td_rew[m] + ((1.f - p.td_done[m]) * p.td_gamma_n) * fminf(t1, t2);   // r + (1-d) gamma^n min Q'
-          dq = p.td_q[((long long)g * p.M + m) * p.ldy] - y;
-        }
-        tdacc += dq * dq;
-        dyl[u] = lane == 0 ? p.td_two_over_b * dq : 0.f;
+      if constexpr (TD) {   // wave-uniform addresses (one request each), no branch around the loads: a row past the end re-reads row 0
+        const long long mc = ok ? m : 0;
+        const float t1 = p.td_qt[mc * p.ldy], t2 = p.td_qt[((long long)p.M + mc) * p.ldy];
+        const float rw = p.td_rew[mc], dn_ = p.td_done[mc], qv = p.td_q[((long long)g * p.M + mc) * p.ldy];
+        tdq[u] = qv; tdr[u] = rw; tdd[u] = dn_; tdt[u] = fminf(t1, t2);
+        dyl[u] = ok ? 1.f : 0.f;   // (finished below, once every load of the group has been requested)
       } else {
         dyl[u] = (ok && lane < p.N) ? dY[(long long)m * p.ldy + lane] : 0.f;
+      }
+    }
+    if constexpr (TD) {
+#pragma unroll
+      for (int u = 0; u < RIF; ++u) {
+        const float y = tdr[u] + ((1.f - tdd[u]) * p.td_gamma_n) * tdt[u];   // r + (1-d) gamma^n min Q'   (pql_v_learner.py:105)
+        const float dq = dyl[u] != 0.f ? tdq[u] - y : 0.f;
+        tdacc += dq * dq;
+        dyl[u] = lane == 0 ? p.td_two_over_b * dq : 0.f;
       }
     }
 #pragma unroll

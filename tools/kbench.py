@@ -108,6 +108,9 @@ def main():
         apply_optimizer(scratch_arena[0], ws["grads"], v.opt, scratch_arena[3], 5e-4, 0.5, 0.05, 1.0, dev, layout=cl,
                         packed=v.pk_critic, packed_target=v.pk_target)
 
+    def sec_opt_nopack():   # the same without the fragment-ordered re-pack (what the scattered 16-B pack stores cost)
+        apply_optimizer(scratch_arena[0], ws["grads"], v.opt, scratch_arena[3], 5e-4, 0.5, 0.05, 1.0, dev)
+
     def rate(fn, n):   # free-running learner steps (own stream, hipGraph replay): wall clock around a full device sync
         import time
         for _ in range(8):
@@ -124,7 +127,7 @@ def main():
 
     sections = {"actor": lambda: graph_time(sec_actor, dev), "target": lambda: graph_time(sec_target, dev),
                 "critic": lambda: graph_time(sec_critic, dev), "bwd": lambda: graph_time(sec_bwd, dev),
-                "opt": lambda: graph_time(sec_opt, dev), "vstep": lambda: rate(v.learn, ns.steps),
+                "opt": lambda: graph_time(sec_opt, dev), "opt_nopack": lambda: graph_time(sec_opt_nopack, dev), "vstep": lambda: rate(v.learn, ns.steps),
                 "pstep": lambda: rate(p.learn, ns.steps)}
     want = [s for s in ns.sections.split(",") if s]
     variants = ns.variants.split(";")

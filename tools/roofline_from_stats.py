@@ -38,38 +38,44 @@ def main():
     crit = [O + A] + h + [1]
     actor = [O] + h + [A]
     params_c = 2 * (macs(crit) + sum(crit[1:]))
-    # (name prefix, label, launches per V step, unit work per step, kind)
+    # V steps in the trace = launches of the optimiser kernel (one per step); every other kernel's launches per step follow from
+    # the CSV's own call counts (tools/profile_bench.sh traces with --burn-in-ms 0 --no-roofline: nothing but steps launches them)
+    opt = find("k_adamw")
+    steps = int(opt["Calls"]) if opt else 0
+    per_batch = B * ((2 * O + A) * 4 + 4 + 1 + 8 + (2 * O + A) * 4 + 4 + 4)
+    # (name prefix, label, unit work per V step, kind)
     table = [
-        ("void k_mlp_fwd_fused<2, 2>", "twin-critic fused forward (target + current)", 2, 2 * (2.0 * B * 2 * macs(crit)), "flop"),
-        ("void k_mlp_fwd_fused<1, 2>", "actor fused forward (+tanh, target noise)", 1, 2.0 * B * macs(actor), "flop"),
-        ("void k_gemm<1, 128, 128", "dX GEMMs (+ELU') of hidden layers 3 and 2, both nets", 2,
+        ("void k_mlp_fwd_fused<2, 2>", "twin-critic fused forward (target + current)", 2 * (2.0 * B * 2 * macs(crit)), "flop"),
+        ("void k_mlp_fwd_fused<1, 2>", "actor fused forward (+tanh, target noise)", 2.0 * B * macs(actor), "flop"),
+        ("void k_gemm<1, 128, 128", "dX GEMMs (+ELU') of hidden layers 3 and 2, both nets", 2.0 * B * 2 * (h[2] * h[1] + h[1] * h[0]), "flop"),
+        ("void k_gemm<2, 128, 128", "dW GEMMs of hidden layers 3 and 2, both nets (16 batch splits)",
          2.0 * B * 2 * (h[2] * h[1] + h[1] * h[0]), "flop"),
-        ("void k_gemm<2, 128, 128", "dW GEMMs of hidden layers 3 and 2, both nets (16 batch splits)", 2,
-         2.0 * B * 2 * (h[2] * h[1] + h[1] * h[0]), "flop"),
-        ("void k_gemm<2, 64, 64", "dW GEMM of layer 1, both nets", 1, 2.0 * B * 2 * (O + A) * h[0], "flop"),
-        ("void k_skinny_bwd<1, 1>", "Q-head backward: dX + dW + db in one pass, both nets", 1, 2.0 * B * h[2] * 4 * 2, "byte"),
-        ("k_reduce_slabs", "sum of the 16 dW slabs (+ head fold + sum g^2)", 1, params_c * 4.0 * 17, "byte"),
-        ("k_adamw", "clip + AdamW + Polyak + re-pack", 1, params_c * 36.0, "byte"),
-        ("void k_replay_gather_fast", "fused replay gather + normalise + cat", 1,
-         B * ((2 * O + A) * 4 + 4 + 1 + 8 + (2 * O + A) * 4 + 4 + 4), "byte"),
-        ("k_td_mse", "TD target + MSE loss + dL/dQ", 1, B * (4 * 4 + 2 * 4 + 2 * 4), "byte"),
+        ("void k_gemm<2, 64, 64", "dW GEMM of layer 1, both nets", 2.0 * B * 2 * (O + A) * h[0], "flop"),
+        ("void k_gemm<2, 128, 64", "dW GEMM of layer 1, both nets", 2.0 * B * 2 * (O + A) * h[0], "flop"),
+        ("void k_skinny_bwd<1, 1", "Q-head backward: TD target + MSE + dX + dW + db in one pass, both nets", 2.0 * B * h[2] * 4 * 2, "byte"),
+        ("k_reduce_slabs", "sum of the 16 dW slabs (+ head fold + sum g^2)", params_c * 4.0 * 17, "byte"),
+        ("k_adamw", "clip + AdamW + Polyak + re-pack (+ loss fold)", params_c * 36.0, "byte"),
+        ("void k_replay_gather_fast", "fused replay gather + normalise + cat (one launch per 8 steps)", per_batch, "byte"),
+        ("k_philox_draws", "randint + normal draws of 8 steps (torch's numbers)", B * 8 + B * A * 4, "byte"),
+        ("k_td_mse", "TD target + MSE loss + dL/dQ", B * (4 * 4 + 2 * 4 + 2 * 4), "byte"),
     ]
-    print(f"| kernel | role | launches / V step | avg us / launch | work / step | achieved | roof | frac |")
-    print("|---|---|---|---|---|---|---|---|")
+    print("| kernel | role | launches / V step | avg us / launch | us / V step | work / step | achieved | roof | frac |")
+    print("|---|---|---|---|---|---|---|---|---|")
     tot_us = 0.0
-    for prefix, label, n, work, kind in table:
+    for prefix, label, work, kind in table:
         r = find(prefix)
-        if r is None:
+        if r is None or not steps:
             continue
         us = float(r["AverageNs"]) / 1e3
+        n = int(r["Calls"]) / steps
+        if prefix == "void k_mlp_fwd_fused<1, 2>":
+            n = round(n)   # (the rollout's policy forward uses the same kernel during set-up)
         tot_us += n * us
-        if kind == "flop":
-            ach = work / (n * us * 1e-6) / 1e12
-            print(f"| `{prefix.replace('void ', '')}…` | {label} | {n} | {us:.1f} | {work / 1e9:.2f} GFLOP | {ach:.1f} TFLOP/s | MFMA {PEAK_TF} | {ach / PEAK_TF:.2f} |")
-        else:
-            ach = work / (n * us * 1e-6) / 1e12
-            print(f"| `{prefix.replace('void ', '')}…` | {label} | {n} | {us:.1f} | {work / 1e6:.2f} MB | {ach:.2f} TB/s | HBM {PEAK_TB} | {ach / PEAK_TB:.2f} |")
-    print(f"\nSum of the listed launches: {tot_us:.0f} us per V step (the torch RNG launches and the graph's generator fills are not listed).")
+        ach = work / (n * us * 1e-6) / 1e12
+        unit, peak, scale, wu = ("TFLOP/s", PEAK_TF, 1e9, "GFLOP") if kind == "flop" else ("TB/s", PEAK_TB, 1e6, "MB")
+        print(f"| `{prefix.replace('void ', '')}…` | {label} | {n:.3g} | {us:.1f} | {n * us:.1f} | {work / scale:.2f} {wu} | {ach:.2f} {unit} | "
+              f"{'MFMA' if kind == 'flop' else 'HBM'} {peak} | {ach / peak:.2f} |")
+    print(f"\n{steps} V steps in the trace; sum of the listed launches: {tot_us:.0f} us per V step.")
 
 
 if __name__ == "__main__":
