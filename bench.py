@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--burn-in-ms", type=float, default=120.0,
                     help="set-up: keep the matrix pipes busy this long (the V step's MFMA launches on scratch buffers; no learner "
                          "state is touched) right before the warm-up steps.  After ANY idle gap of >= 10 ms the MFMA kernels of this "
-                         "GPU run ~14 %% slow and recover over the next ~30 ms of load (tools/debug/ramp_after_idle.py), and set-up "
+                         "GPU run ~14 %% slow and recover over the next ~30 ms of load (measured in round 2), and set-up "
                          "ends in such gaps: without this a 20-step timed region sits on that ramp.  Recorded in config.burn_in_ms; "
                          "0 disables")
     ap.add_argument("--no-graph", action="store_true")

@@ -102,9 +102,15 @@ int pqlk_replay_gather(const PqlReplayDesc* ring, const int64_t* idx, int64_t b,
  * with ld_o) are written (pql_p_learner.py:49-52).
  * clamp5 is a flag word: bit 0 = apply the +-5 clamp; bit 1 (PQLK_GATHER_PADS_ZERO) = the caller guarantees that the pad
  * columns [O+A, ld_sa) / [O, ld_o) of the destinations are already zero (allocated zeroed, written by nothing else), so
- * the kernel does not re-zero them on every call (11 % fewer bytes stored at cfg 5). */
+ * the kernel does not re-zero them on every call (11 % fewer bytes stored at cfg 5).  Launch-shape overrides for
+ * tools/bench_gather.py ride in the same word, so the library keeps no tuning state between calls: bit 2 = non-temporal
+ * record loads, bits 8-11 = rows in flight per wave (1, 2, 4, 8; 0 = automatic), bits 12-17 = resident waves per CU
+ * (0 = automatic). */
 #define PQLK_GATHER_CLAMP5 1
 #define PQLK_GATHER_PADS_ZERO 2
+#define PQLK_GATHER_NT_LOADS 4
+#define PQLK_GATHER_ROWS_IN_FLIGHT(r) (((r) & 15) << 8)
+#define PQLK_GATHER_WAVES_PER_CU(w) (((w) & 63) << 12)
 int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t* idx, int64_t b,
                              const float* mean, const float* var, float eps, int clamp5,
                              float* x_sa, int64_t ld_sa, float* xn_sa, float* xn_obs, int64_t ld_o,
@@ -248,10 +254,6 @@ int pqlk_philox_draws(uint64_t seed, int64_t base_offset, int32_t base_step, con
                       pqlk_stream_t stream);
 /* Philox offset increment of one torch draw of `numel` elements (4 values per counter block, at most 2048 x 256 threads). */
 int64_t pqlk_philox_increment(int64_t numel);
-
-/* Tuning hook of the replay gather (tools/bench_gather.py): rows in flight per wave (1, 2, 4, 8), resident waves per CU,
- * "skip the pad stores" and non-temporal record loads for the next launches (0 = automatic / off). */
-int pqlk_tune_gather(int rows_in_flight, int waves_per_cu, int nopad, int nt_loads);
 
 /* DPG backward through the frozen twin critic (pql_p_learner.py:55-58): the input gradient of pqlk_mlp_backward's
  * (grads = NULL, dx + dx_tanh_of) form.  With scalar Q heads the gradient of min(Q1, Q2) reaches one net per sample, so the

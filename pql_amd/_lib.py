@@ -38,7 +38,6 @@ PROTOTYPES = {
     "pqlk_replay_insert": (C.c_int, [C.POINTER(PqlReplayDesc), _I64, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P]),
     "pqlk_replay_gather": (C.c_int, [C.POINTER(PqlReplayDesc), _P, _I64, _P, _P, _P, _P, _P, _P]),
     "pqlk_replay_gather_fused": (C.c_int, [C.POINTER(PqlReplayDesc), _P, _I64, _P, _P, _F, C.c_int, _P, _I64, _P, _P, _I64, _P, _P, _P]),
-    "pqlk_tune_gather": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "pqlk_philox_draws": (C.c_int, [C.c_uint64, _I64, _I32, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _P]),
     "pqlk_philox_increment": (_I64, [_I64]),
     "pqlk_nstep_push_emit": (C.c_int, [_P, _I64, _I32, _I32, _I32, _I64, _I64, _P, _P, _P, _P, _P, C.POINTER(C.c_float),

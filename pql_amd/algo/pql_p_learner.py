@@ -161,7 +161,7 @@ class PQLPLearner:
         ws["dy_c"] = torch.zeros((2, B, cl.ld_out), **f)
         ws["dz_a"] = torch.zeros((1, B, ws["ld_a"]), **f)   # dL/d(actor pre-tanh); pad columns stay zero
         ws["grads"] = torch.zeros(al.total, **f)
-        ws["splits"] = default_splits(B)
+        ws["splits"] = default_splits(B, _cfg_get(self.cfg.algo, "dw_splits", 16))
         ws["bwd_c"] = torch.empty(int(L.lib.pqlk_dpg_backward_ws_floats(C.byref(cl.desc), B)), **f)
         ws["owner"] = torch.zeros(B, dtype=torch.uint8, device=self.device)   # which net(s) own each sample's min(Q1, Q2)
         ws["bwd_a"] = torch.empty(al.bwd_ws_floats(B, ws["splits"]), **f)

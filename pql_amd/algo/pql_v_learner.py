@@ -361,7 +361,7 @@ class PQLVLearner:
         ws["acts_c"] = torch.empty(cl.acts_floats(B), **f)
         ws["dy"] = torch.zeros((2, B, cl.ld_out), **f)
         ws["grads"] = torch.zeros(cl.total, **f)
-        ws["splits"] = default_splits(B)
+        ws["splits"] = default_splits(B, _cfg_get(self.cfg.algo, "dw_splits", 16))
         ws["bwd"] = torch.empty(cl.bwd_ws_floats(B, ws["splits"]), **f)
         ws["scratch"] = torch.zeros(2048, **f)
         # scalar twin heads: TD target + MSE + dL/dQ are formed inside the head's backward pass (one launch less)

@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "pqlk_common.h"
+int g_pqlk_knob[16] = {};   // experiment switches of the current tuning round (tools/kbench.py); removed once a variant is chosen
 #include "skinny.h"
 #include "fused.h"
 
@@ -61,8 +62,6 @@ struct GemmP {
 #include "narrow.h"
 #include "minnet.h"
 
-// experiment switches of the current tuning round (tools/kbench.py); removed once a variant is chosen
-int g_pqlk_knob[16] = {};
 extern "C" int pqlk_debug_knob(int key, int value) {
   if (key < 0 || key >= 16) return PQLK_E_RANGE;
   g_pqlk_knob[key] = value;

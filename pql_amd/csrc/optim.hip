@@ -56,6 +56,30 @@ __device__ __forceinline__ long long packed_index(const PackSpec& ps, long long 
   return -1;
 }
 
+// Which 16-B quad of the arena thread number `q` (linear over the arena's quads) works on, and where that quad lives in the
+// fragment-ordered copy (-1: nowhere).  Outside the packed weight blocks: quad q itself.  Inside one (N x K, both multiples of 32)
+// the block's quads are dealt out in tiles of 32 rows x 32 columns, 256 consecutive thread numbers per tile, thread t of a tile
+// taking (row t / 8, quad t % 8): eight lanes still cover one 128-B line of every arena stream, and the eight ROWS a wave holds for
+// a given (k8, h) are eight CONSECUTIVE 16-B slots of the packed copy (slot = (tile, k8, h, r)), so the re-pack stores go out as
+// whole 128-B runs.  With the identity map the same stores were isolated 16-B writes 512 B apart: 3.4 of the launch's ~10 us
+// (tools/kbench.py opt / opt_nopack, round 3).  A bijection on each block's quads, elementwise arithmetic: same bits.
+__device__ __forceinline__ long long adam_quad(const PackSpec& ps, long long q, long long& packed) {
+  packed = -1;
+#pragma unroll 1
+  for (int e = 0; e < ps.n; ++e) {
+    const long long q0 = ps.w_off[e] >> 2, q1 = ps.w_end[e] >> 2;
+    if (q >= q0 && q < q1) {
+      const long long rel = q - q0;
+      const int K = ps.K[e], kb = K >> 5;
+      const int jb = (int)(rel >> 8), t = (int)(rel & 255);
+      const int tr = jb / kb, cb = jb - tr * kb, r = t >> 3, cq = t & 7;
+      packed = ps.p_off[e] + (((long long)tr * (K >> 3) + 4 * cb + (cq >> 1)) * 64 + (cq & 1) * 32 + r) * 4;
+      return q0 + (long long)(32 * tr + r) * (K >> 2) + 8 * cb + cq;
+    }
+  }
+  return q;
+}
+
 struct AdamC {
   float lr_wd_decay;  // 1 - lr*wd
   float w1;           // 1 - b1      (lerp weight)
@@ -87,10 +111,12 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
   const int64_t n4 = vec ? (n >> 2) : 0;
   const int64_t q0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
   f4 g4n = f4{0.f, 0.f, 0.f, 0.f}, p4n = g4n, m4n = g4n, v4n = g4n, t4n = g4n;
+  long long pkn = -1;                                         // packed-copy offset of the quad held in *4n
+  int64_t qan = q0 < n4 ? adam_quad(ps, q0, pkn) : 0;         // ... and its place in the arena
   if (q0 < n4) {
-    g4n = reinterpret_cast<const f4*>(g)[q0];
-    p4n = reinterpret_cast<f4*>(p)[q0]; m4n = reinterpret_cast<f4*>(m)[q0]; v4n = reinterpret_cast<f4*>(v)[q0];
-    if (target) t4n = reinterpret_cast<f4*>(target)[q0];
+    g4n = reinterpret_cast<const f4*>(g)[qan];
+    p4n = reinterpret_cast<f4*>(p)[qan]; m4n = reinterpret_cast<f4*>(m)[qan]; v4n = reinterpret_cast<f4*>(v)[qan];
+    if (target) t4n = reinterpret_cast<f4*>(target)[qan];
   }
   // Preamble, ONE barrier: every block re-reduces the (<= 2048) squared-norm partials in the same fixed order (strided
   // per-thread sums -> xor-shuffle tree per wave -> the four waves in order) -> identical clip factor everywhere; the two
@@ -134,16 +160,19 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
   };
   // 16-B path: four consecutive parameters per thread.  Arena blocks start on multiples of 32 floats and rows are
   // multiples of 32 long, so an aligned quad never straddles a packed block and maps to ONE 16-B quad of the
-  // fragment-ordered copy (j = k & 3 runs over the quad): the re-pack is a 16-B store too.
+  // fragment-ordered copy (j = k & 3 runs over the quad): the re-pack is a 16-B store too.  Which quad a thread takes:
+  // adam_quad above.
   for (int64_t q4 = q0; q4 < n4; q4 += (int64_t)gridDim.x * 256) {
-    const int64_t i = q4 << 2;
+    const int64_t qa = qan;
+    const long long pk = pkn;
     const f4 g4 = g4n;
     f4 p4 = p4n, m4 = m4n, v4 = v4n, t4 = t4n;
     const int64_t qn = q4 + (int64_t)gridDim.x * 256;   // the next quad of this thread, requested before this one is stored
     if (qn < n4) {
-      g4n = reinterpret_cast<const f4*>(g)[qn];
-      p4n = reinterpret_cast<f4*>(p)[qn]; m4n = reinterpret_cast<f4*>(m)[qn]; v4n = reinterpret_cast<f4*>(v)[qn];
-      if (target) t4n = reinterpret_cast<f4*>(target)[qn];
+      qan = adam_quad(ps, qn, pkn);
+      g4n = reinterpret_cast<const f4*>(g)[qan];
+      p4n = reinterpret_cast<f4*>(p)[qan]; m4n = reinterpret_cast<f4*>(m)[qan]; v4n = reinterpret_cast<f4*>(v)[qan];
+      if (target) t4n = reinterpret_cast<f4*>(target)[qan];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -151,16 +180,13 @@ __global__ __launch_bounds__(256) void k_adamw(float* __restrict__ p, const floa
       upd(g4[u], pi, mi, vi, ti);
       p4[u] = pi; m4[u] = mi; v4[u] = vi; t4[u] = ti;
     }
-    reinterpret_cast<f4*>(p)[q4] = p4;
-    reinterpret_cast<f4*>(m)[q4] = m4;
-    reinterpret_cast<f4*>(v)[q4] = v4;
-    if (target) reinterpret_cast<f4*>(target)[q4] = t4;
-    if (ps.n > 0) {
-      const long long q = packed_index(ps, i);
-      if (q >= 0) {
-        *reinterpret_cast<f4*>(ps.packed_p + q) = p4;
-        if (target && ps.packed_t) *reinterpret_cast<f4*>(ps.packed_t + q) = t4;
-      }
+    reinterpret_cast<f4*>(p)[qa] = p4;
+    reinterpret_cast<f4*>(m)[qa] = m4;
+    reinterpret_cast<f4*>(v)[qa] = v4;
+    if (target) reinterpret_cast<f4*>(target)[qa] = t4;
+    if (pk >= 0) {
+      *reinterpret_cast<f4*>(ps.packed_p + pk) = p4;
+      if (target && ps.packed_t) *reinterpret_cast<f4*>(ps.packed_t + pk) = t4;
     }
   }
   for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {   // tail / unaligned

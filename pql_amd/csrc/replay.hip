@@ -244,12 +244,7 @@ __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __rest
 // decode, destination and normalisation constants of a lane depend only on its chunk index, so they are computed ONCE
 // per kernel and the per-row work is load -> (sub, IEEE div, clamp) x4 -> one or two 16-B stores.  The generic kernel
 // above re-decodes the field per row and is instruction-issue bound (~450 instructions per row).
-// tuning hooks (pqlk_tune_gather): 0 = automatic
-static int g_gather_R = 0, g_gather_waves_per_cu = 0, g_gather_nopad = 0, g_gather_nt = 0;
-extern "C" int pqlk_tune_gather(int rows_in_flight, int waves_per_cu, int nopad, int nt_loads) {
-  g_gather_R = rows_in_flight; g_gather_waves_per_cu = waves_per_cu; g_gather_nopad = nopad; g_gather_nt = nt_loads;
-  return PQLK_OK;
-}
+// (launch-shape overrides for tools/bench_gather.py arrive in the call's flag word: no state between calls)
 
 template <bool HAS_NORM, int R>
 __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restrict__ records, RecLayout L, int64_t capacity,
@@ -400,7 +395,8 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
                                         float* xn_sa, float* xn_obs, int64_t ld_o, float* rew, float* done,
                                         pqlk_stream_t stream) {
   const int clamp5 = flags & PQLK_GATHER_CLAMP5;
-  const int write_pads = ((flags & PQLK_GATHER_PADS_ZERO) || g_gather_nopad) ? 0 : 1;
+  const int write_pads = (flags & PQLK_GATHER_PADS_ZERO) ? 0 : 1;
+  const int tune_R = (flags >> 8) & 15, tune_wpc = (flags >> 12) & 63, nt_loads = (flags & PQLK_GATHER_NT_LOADS) ? 1 : 0;
   PQLK_REQUIRE(ring && ring->records && idx, PQLK_E_NULL);
   PQLK_REQUIRE(ring->obs_dim > 0 && ring->capacity > 0 && b >= 0, PQLK_E_SHAPE);
   RecLayout L = rec_layout(ring->obs_dim, ring->act_dim);
@@ -436,16 +432,16 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
     // 20.2 us at best -- no better than this kernel, i.e. the limit is the memory system's rate for this mix (about 4 TB/s of
     // bytes moved), not the way one wave's loads and stores queue.
     int R = 2;
-    if (g_gather_R) R = g_gather_R;
+    if (tune_R == 1 || tune_R == 2 || tune_R == 4 || tune_R == 8) R = tune_R;
     const int halves = nchunk > 64 ? 2 : 1;   // 1-2 KiB records: two waves per row
     const int rows_blk = 4 / halves * R;
     int64_t fb = (b + rows_blk - 1) / rows_blk;
-    const int wpc = g_gather_waves_per_cu ? g_gather_waves_per_cu : 24;
+    const int wpc = tune_wpc ? tune_wpc : 24;
     if (fb > 256 * (int64_t)wpc / 4) fb = 256 * (int64_t)wpc / 4;
     const dim3 g((unsigned)fb), t(256);
 #define PQLK_GATHER_FAST(NORM, RR) \
     hipLaunchKernelGGL((k_replay_gather_fast<NORM, RR>), g, t, 0, pqlk_s(stream), ring->records, L, ring->capacity, idx, b, mean, var, \
-                       eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done, write_pads, g_gather_nt, halves)
+                       eps, clamp5, x_sa, ld_sa, xn_sa, xn_obs, ld_o, rew, done, write_pads, nt_loads, halves)
 #define PQLK_GATHER_FAST_R(NORM) \
     do { if (R == 1) PQLK_GATHER_FAST(NORM, 1); else if (R == 2) PQLK_GATHER_FAST(NORM, 2); else if (R == 4) PQLK_GATHER_FAST(NORM, 4); \
          else PQLK_GATHER_FAST(NORM, 8); } while (0)

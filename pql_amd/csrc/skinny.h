@@ -425,10 +425,10 @@ static inline int skinny_bwd_nb(int n_out) { return n_out == 1 ? 1 : (n_out <= 4
 static inline bool skinny_bwd_fused_ok(int n_out, int k_padded) {
   return n_out <= SKINNY_MAX_N && k_padded <= SKINNY_MAX_K && skinny_bwd_nb(n_out) * skinny_bwd_ch(k_padded) <= 16;
 }
-// rows per block: 64, halved while the grid would leave CUs without a block (one net at batch 8192: 32 rows -> 256 blocks)
+// rows per block: 64, halved while the grid has fewer than two blocks per CU (twin critic at batch 8192: 32 rows -> 512 blocks)
 static inline int skinny_bwd_rows(int64_t m, int groups) {
   int r = SKB_ROWS;
-  while (r > 16 && ((m + r - 1) / r) * groups < 256) r >>= 1;
+  while (r > 16 && ((m + r - 1) / r) * groups < 512) r >>= 1;   // two blocks per CU (one: V step +1.4 us, P step +1.3; round 3)
   return r;
 }
 static inline int skinny_bwd_blocks(int64_t m, int groups) { const int r = skinny_bwd_rows(m, groups); return (int)((m + r - 1) / r); }

@@ -75,11 +75,9 @@ class ArenaLayout:
         return self.n_nets * sum(self.dims[l + 1] * self.dims[l] + self.dims[l + 1] for l in range(self.n_layers))
 
 
-def default_splits(B: int) -> int:
-    """Batch splits of the dW GEMM: enough (net x tile x split) blocks to cover 256 CUs, >= 256 rows each."""
-    import os
-    cap = int(os.environ.get("PQLK_SPLITS", 16))   # tuning override
-    return int(max(1, min(cap, B // 512)))
+def default_splits(B: int, cap: int = 16) -> int:
+    """Batch splits of the dW GEMM: enough (net x tile x split) blocks to cover 256 CUs, >= 512 rows each (cap: `algo.dw_splits`)."""
+    return int(max(1, min(int(cap), B // 512)))
 
 
 def pad_cols(x: torch.Tensor, ld: int) -> torch.Tensor:

@@ -222,6 +222,18 @@ def test_bench_launches_its_own_ranks_for_data_parallel():
     assert line["value"] > 0 and line["steps"] == 16 and line["scaling"] == "weak"
 
 
+def test_bench_strong_scaling_shards_the_job_over_the_ranks():
+    """`--scaling strong`: --num-envs / --replay / --batch are the JOB's sizes (BASELINE configs[3] as written) and every rank takes
+    1 / N of each; `value` then counts steps of the job's batch, not batch-sized steps summed over ranks."""
+    line = _run_bench("--gpus", "2", "--backend", "gloo", "--share-gpu", "--scaling", "strong")
+    cfg = line["config"]
+    assert line["scaling"] == "strong" and cfg["ranks"] == 2
+    assert cfg["per_rank"] == {"num_envs": 128, "replay_rows": 10000, "batch": 512}
+    assert cfg["job"] == {"num_envs": 256, "replay_rows": 20000, "batch": 1024}
+    assert abs(line["value"] - line["steps"] / (line["ms_per_step"] * line["steps"] * 1e-3)) < 1e-6 * line["value"]   # no x ranks
+    assert abs(line["env_steps_per_s"] - line["value"] / 8 * 256) < 1e-6 * line["env_steps_per_s"]
+
+
 def test_bench_split2_layout_rehearsed_on_one_card():
     """BASELINE configs[2] entry: simulator on GPU 0, learners on GPU 1, copy-stream hand-offs.  With --share-gpu both are
     cuda:0 and every hand-off still goes through the Shipper path."""

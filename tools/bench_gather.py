@@ -12,10 +12,13 @@ import torch  # noqa: E402
 from pql_amd import _lib as L  # noqa: E402
 from pql_amd.replay.simple_replay import ReplayBuffer  # noqa: E402
 
-CFG = {"cfg2": (88, 16, 8192, 1_000_000), "cfg5": (108, 21, 32768, 5_000_000), "cfg4": (211, 20, 8192, 2_000_000)}
+# (obs, act, rows per launch, ring rows): one batch per launch (the per-step path) and the launches that serve 8 V-steps at once
+CFG = {"cfg2": (88, 16, 8192, 1_000_000), "cfg5": (108, 21, 32768, 5_000_000), "cfg4": (211, 20, 8192, 2_000_000),
+       "cfg2x8": (88, 16, 8 * 8192, 1_000_000), "cfg5x8": (108, 21, 8 * 32768, 5_000_000), "cfg4x8": (211, 20, 8 * 8192, 2_000_000)}
 
 
 def run(name, iters=30):
+    iters = max(4, min(iters, (1 << 23) // CFG[name][2]))   # (bound the index tensor for the 8-batch launches)
     O, A, B, cap = CFG[name]
     dev = torch.device("cuda:0")
     rb = ReplayBuffer(cap, (O,), A, dev)
@@ -29,19 +32,19 @@ def run(name, iters=30):
     alg = B * ((2 * O + A) * 4 + 4 + 1 + 8 + (2 * O + A) * 4 + 4 + 4)
     real = B * (rb.ring.rec_ld * 4 + 8 + 2 * ld_sa * 4 + 8)
 
-    def one(i, norm=True):
+    def one(i, norm=True, flags=1):
         L.check(L.lib.pqlk_replay_gather_fused(C.byref(rb.ring.desc), L.ptr(idx[i]), B, L.ptr(mean) if norm else None,
-                                               L.ptr(var) if norm else None, 1e-4, 1, L.ptr(x_sa), ld_sa, L.ptr(xn_sa), None, ld_o,
+                                               L.ptr(var) if norm else None, 1e-4, flags, L.ptr(x_sa), ld_sa, L.ptr(xn_sa), None, ld_o,
                                                L.ptr(rew), L.ptr(done), L.stream(dev)))
 
-    def timed(norm=True):
-        one(0, norm)
+    def timed(norm=True, flags=1):
+        one(0, norm, flags)
         g = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.graph(g, stream=side):
             for i in range(iters):
-                one(2 + i, norm)
+                one(2 + i, norm, flags)
         g.replay()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -53,10 +56,9 @@ def run(name, iters=30):
         for wpc in (12, 16, 24, 32):
             for nopad in (0, 1):
                 for nt in (0, 1):
-                    L.lib.pqlk_tune_gather(R, wpc, nopad, nt)
-                    us = min(timed() for _ in range(3))
+                    flags = 1 | (2 if nopad else 0) | (4 if nt else 0) | (R << 8) | (wpc << 12)   # include/pqlk.h: PQLK_GATHER_*
+                    us = min(timed(flags=flags) for _ in range(3))
                     print(f"  R={R} waves/CU={wpc} nopad={nopad} nt={nt}: {us:6.2f} us  alg {alg / us / 1e6:5.2f} TB/s ({alg / us / 1e6 / 8:.3f} of 8)  moved {real / us / 1e6:5.2f} TB/s")
-    L.lib.pqlk_tune_gather(0, 0, 0, 0)
     print(f"  auto, no normalisation: {timed(False):6.2f} us")
 
 

@@ -1,5 +1,5 @@
 """Robustness sweep of scripts/train_pql.py over cfg corners (one process, a few hundred thousand env steps each):
-    python tools/debug/config_sweep.py
+    python tools/config_sweep.py
 Every run must finish, keep its update ratios, and end with finite parameters and losses."""
 import math
 import os
@@ -7,7 +7,7 @@ import sys
 import time
 import traceback
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 

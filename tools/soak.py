@@ -1,14 +1,14 @@
-"""Soak run of scripts/train_pql.py on one MI355X: `python tools/debug/soak.py <seconds> [overrides...]`.
+"""Soak run of scripts/train_pql.py on one MI355X: `python tools/soak.py <seconds> [overrides...]`.
 Samples device memory (allocated / reserved), host RSS and the update counters every few seconds while the entry point runs,
 and reports whether anything grows or goes non-finite.  Example:
-    python tools/debug/soak.py 60 task=AllegroHand algo.async_learners=True
+    python tools/soak.py 60 task=AllegroHand algo.async_learners=True
 """
 import os
 import sys
 import threading
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
