@@ -48,20 +48,8 @@ struct FusedP {
   const float* draw;                           // (B, head_n) standard-normal draw for HEAD_TANH_NOISE
   float* out2;                                 // optional second destination of the output (net 0), row stride ld_out2
   float noise_std, noise_clip;
-#if defined(PQLK_FP_CLK)   // tuning probe only (tools/probes/fused_probe.hip): shader-clock stamps of one wave
-  long long* clk;
-#endif
 };
 
-#if defined(PQLK_FP_CLK)
-#define FP_TICK(i) if (clk && lane == 0) clk[i] = clock64()
-#define FP_CLKPARAM , long long* clk
-#define FP_CLKARG , clk
-#else
-#define FP_TICK(i)
-#define FP_CLKPARAM
-#define FP_CLKARG
-#endif
 
 __device__ __forceinline__ float fused_elu(float x) { return x > 0.f ? x : __expf(x) - 1.f; }
 
@@ -134,12 +122,11 @@ template <int R, int TPW, int TM, int D>
 __device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, int K8, int ntiles, const float4* __restrict__ packed_l,
                                             int bias_lds4, float* __restrict__ gout, int g_ld, int row0, int B, int wave, int lane,
                                             const float4* __restrict__ packed_n, int K8n, int ntiles_n, int tpw_n,
-                                            float* __restrict__ gprev, int nprev4 FP_CLKPARAM) {
+                                            float* __restrict__ gprev, int nprev4) {
   const int r = lane & 31, h = lane >> 5;
   const int t0 = wave * TPW;
   const bool active = t0 < ntiles;   // wave-uniform
   const float4* lds4 = reinterpret_cast<const float4*>(fsm);
-  FP_TICK(0);
   // (a stagger of the SIMD partners -- waves 4-7 entering each layer 256 / 512 / 1024 cycles behind waves 0-3 -- measured
   //  +0.5 / 0 / -0.3 % on the V step, inside the noise: not used)
   // Deferred stash: this layer's INPUT buffer is the previous layer's output.  Writing it to HBM from here, spread over
@@ -189,10 +176,8 @@ __device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, in
     srow += sdq; sc4 += sdm;
     if (sc4 >= nprev4) { sc4 -= nprev4; ++srow; }
   }
-  FP_TICK(1);
   if (packed_n) fused_ring_fill<TM, D>(bq, packed_n, K8n, ntiles_n, tpw_n, wave, lane);   // ahead of this layer's epilogue
   __syncthreads();   // A: every wave is done reading this layer's input
-  FP_TICK(2);
   if (active) {
     // lane (r, h) owns row r of each row tile, columns 32*tile + 8q + 4h + {0..3} (transposed-tile accumulator layout)
     float4* out4 = reinterpret_cast<float4*>(fsm);
@@ -219,9 +204,7 @@ __device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, in
       }
     }
   }
-  FP_TICK(3);
   __syncthreads();   // B: the next layer's input is in place
-  FP_TICK(4);
 }
 
 // Output layer fused behind the hidden stack: Linear(K_h -> N <= 32) + {none, tanh, tanh + clipped target-policy noise}
@@ -295,9 +278,6 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
   // four tiles per wave: 16 MFMAs per step already cover the L2 latency with a 2-deep ring (and 4 x 4 quads would spill)
   constexpr int NW = FUSED_NW, D = TM >= 4 ? 2 : PQLK_FUSED_DEEP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#if defined(PQLK_FP_CLK)
-  const long long c_start = clock64();
-#endif
   // XCD-aware block -> (net, row tile) map.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share
   // an L2), and a twin critic's fragment-ordered weights are 2 x 1.8 MB against a 4 MB L2: with both nets on every
   // XCD the weight stream thrashes L2 and falls back to the Infinity Cache.  Even XCD groups take net 0, odd ones
@@ -395,19 +375,15 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
     const float4* packed_n = last ? nullptr : packed_net + (p.p_off[l + 1] >> 2);
     const int K8n = last ? 1 : N >> 3, ntiles_n = last ? 1 : p.dims[l + 2] >> 5;
     const int tpw = tpw_of(ntiles), tpw_n = tpw_of(ntiles_n);
-#if defined(PQLK_FP_CLK)
-    long long* clk = (blockIdx.x == 8 && wave == 0) ? p.clk + 8 + 8 * l : nullptr;
-    if (l == 0 && clk && lane == 0) { p.clk[0] = c_start; p.clk[1] = clock64(); }
-#endif
     if (TM >= 4 && tpw == 4)
       fused_layer<R, (TM >= 4 ? 4 : 1), TM, D>(bq, buf_ld4, K8, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n,
-                                               ntiles_n, tpw_n, gprev, nprev4 FP_CLKARG);
+                                               ntiles_n, tpw_n, gprev, nprev4);
     else if (tpw == 2)
       fused_layer<R, 2, TM, D>(bq, buf_ld4, K8, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n, ntiles_n,
-                               tpw_n, gprev, nprev4 FP_CLKARG);
+                               tpw_n, gprev, nprev4);
     else
       fused_layer<R, 1, TM, D>(bq, buf_ld4, K8, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n, ntiles_n,
-                               tpw_n, gprev, nprev4 FP_CLKARG);
+                               tpw_n, gprev, nprev4);
   }
   if (p.head_n > 0) fused_head<R>(p, pparams, pacts, net, row0, buf_ld4, wave, lane);   // the LDS buffer holds the last hidden layer's output
 }

@@ -19,7 +19,6 @@
 #include <cstdlib>
 #include <type_traits>
 #include "pqlk_common.h"
-int g_pqlk_knob[16] = {};   // experiment switches of the current tuning round (tools/kbench.py); removed once a variant is chosen
 #include "skinny.h"
 #include "fused.h"
 
@@ -56,35 +55,11 @@ struct GemmP {
   const int* perm;
   const int* mn;
   int xcd_remap;      // set by launch_gemm when the grid divides into whole groups per XCD
-  int frag_ahead;     // LDS-DMA loop: MFMA operand fragments are read from LDS one whole stage ahead (set by launch_gemm)
 };
 
 #include "narrow.h"
 #include "minnet.h"
 
-extern "C" int pqlk_debug_knob(int key, int value) {
-  if (key < 0 || key >= 16) return PQLK_E_RANGE;
-  g_pqlk_knob[key] = value;
-  return PQLK_OK;
-}
-__attribute__((constructor)) static void pqlk_knobs_from_env() {   // PQLK_KNOBS="k=v,k=v"
-  const char* e = getenv("PQLK_KNOBS");
-  while (e && *e) {
-    char* end = nullptr;
-    const long k = strtol(e, &end, 10);
-    if (!end || *end != '=') break;
-    const long v = strtol(end + 1, &end, 10);
-    if (k >= 0 && k < 16) g_pqlk_knob[k] = (int)v;
-    e = (*end == ',') ? end + 1 : nullptr;
-  }
-}
-
-#ifndef PQLK_PROBE_DMA_A   // tuning probes only (wrong results): leave one operand's DMA requests out of the k loop
-#define PQLK_PROBE_DMA_A true
-#endif
-#ifndef PQLK_PROBE_DMA_B
-#define PQLK_PROBE_DMA_B true
-#endif
 #define KT_MAX 32   // reduction elements per LDS stage (template parameter KT: 32 or 16)
 #ifndef PQLK_KT
 #define PQLK_KT 16   // 16: half the LDS per block -> a third block per CU; +3 % on the streamed learner step vs 32
@@ -209,10 +184,19 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
   // operand -- the column tiles of one row tile (dX / forward: the same rows of A), all tiles of one (net, batch split) of a dW
   // product (the same rows of dY and X) -- would sit under 8 different L2s and each fetch the operand across the fabric.
   // Re-label: dispatch slot w lands on XCD w % 8; give that XCD whole groups of G sharing tiles, G consecutive slots each.
-  if (p.xcd_remap) {
+  if (p.xcd_remap == 1) {
     const int G = (MODE == MODE_DW) ? gx * gy : gx;
     const int w = bx + gx * (by + gy * bz), sl = w >> 3;
     const int L = ((sl / G) * 8 + (w & 7)) * G + sl % G;
+    bx = L % gx; by = (L / gx) % gy; bz = L / (gx * gy);
+  } else if (p.xcd_remap > 1) {
+    // any grid (p.xcd_remap = number of tiles): the slots of XCD class x = w % 8 take one CONTIGUOUS run of tile numbers, runs of
+    // q or q + 1 tiles (q = tiles / 8) -- bijective for every tile count (cdna_hip_programming.md, 256^2 template).  The compact
+    // dX products (66 x 8 tiles: not a whole number of 8-tile groups per XCD) ran without any re-labelling before: each of
+    // their row tiles of dZ was fetched by eight L2s.
+    const int nt = p.xcd_remap, q = nt >> 3, rr = nt & 7;
+    const int w = bx + gx * (by + gy * bz), x = w & 7;
+    const int L = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (w >> 3);
     bx = L % gx; by = (L / gx) % gy; bz = L / (gx * gy);
   }
   const int m0 = by * BM, n0 = p.n_base + bx * BN;
@@ -242,6 +226,17 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // Compact rows: the last tile of each net's run is mostly padding (a run is padded to a multiple of 128 rows).  A wave whose
+  // WM-row patch holds no sample issues no MFMAs (its rows of C come out zero, as before): the block still takes part in every
+  // DMA request and barrier, but its share of the CU's matrix pipe goes to the co-resident blocks.  The compact grid is 2.03-2.06
+  // tiles per CU, so a few CUs host three blocks and set the launch's length; with this their third block is only as
+  // expensive as its real rows (to WM-row granularity).  ONE wave-uniform branch per stage: per-sub-tile predicates cost registers.
+  bool live = true;
+  if (MODE == MODE_DX && p.perm) {
+    const int c0 = p.mn[0], c1 = p.mn[1], base1 = p.mn[2], r0 = m0 + wm;
+    live = __builtin_amdgcn_readfirstlane((r0 < c0 || (r0 >= base1 && r0 < base1 + c1)) ? 1 : 0) != 0;   // (a scalar branch)
+  }
+
   float dbacc = 0.f;  // DW: partial column sum of dY for row tid % BM of this block's dW tile (bx == 0 only)
 
   // two register tile sets of the interior main loop (function scope: declared inside the group loop they are kept in
@@ -250,26 +245,6 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
   RrTile<BM, KT> a_rr0, a_rr1;
   KcTile<BN, KT> b_kc0, b_kc1;
   RrTile<BN, KT> b_rr0, b_rr1;
-
-  // ELU' operand of the dX epilogue, requested before the k loop (LDS-DMA instantiations only: the register-staged loop has no
-  // VGPRs to spare -- 247 of 256 -- and spilled when this was tried there).  Same (row, 4-column) ownership as the epilogue's
-  // row-wise pass; the requests are older than every DMA request, so the loop's first counted wait retires them.
-  constexpr int PF_LPR = WN / 4, PF_RPI = 64 / PF_LPR, PF_N = 32 / PF_RPI;
-  constexpr bool AUX_PF = DMA && MODE == MODE_DX && EPI == EPI_DELU;
-  f4v hpre[AUX_PF ? MI : 1][AUX_PF ? PF_N : 1];
-  if (AUX_PF && !p.frag_ahead) {   // (with the fragments a stage ahead the registers go to the second fragment set instead)
-    const float* auxw = p.aux + (long long)g0 * p.sAux;
-    const int prow = lane / PF_LPR, pc4 = lane % PF_LPR;
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-      for (int it = 0; it < PF_N; ++it) {
-        const long long grow = m0 + wm + 32 * i + it * PF_RPI + prow;
-        long long arow = grow;
-        if (p.perm) { const int pr = p.perm[grow]; arow = pr < 0 ? 0 : pr; }   // pad rows: dZ is zero anyway
-        hpre[i][it] = *reinterpret_cast<const f4v*>(auxw + arow * p.ldaux + n0 + wn + 4 * pc4);
-      }
-  }
 
   for (int g = g0; g < g1; ++g) {
     const float* A = p.A + (long long)g * p.sA;
@@ -297,19 +272,10 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
         }
       }
 
+      if (!live) return;   // (compact rows: a patch of padding only)
 #pragma unroll
       for (int k8 = 0; k8 < KT / 8; ++k8) {
         float af[MI][4], bf[NJ][4];
-#if defined(PQLK_PROBE_NOLDS)   // tuning probe only: operands from registers, pure MFMA issue rate
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) { af[i][t] = __int_as_float(lane + kt + t + i); asm volatile("" : "+v"(af[i][t])); }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-          for (int t = 0; t < 4; ++t) { bf[j][t] = __int_as_float(lane - kt + t + j); asm volatile("" : "+v"(bf[j][t])); }
-#else
         (void)kt;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -332,7 +298,6 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
             for (int t = 0; t < 4; ++t) bf[j][t] = sb[(8 * k8 + 4 * h + t) * B_RLD + ((wn + 32 * j + r) ^ (DMA ? 32 * h : 0))];
           }
         }
-#endif
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -384,11 +349,9 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
 #define PQLK_DMA(STG)                                                                                                          \
   do {                                                                                                                         \
     _Pragma("unroll") for (int u = 0; u < AI; ++u)                                                                             \
-      if (PQLK_PROBE_DMA_A)                                                                                                    \
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"                                           \
                    ::"s"(lds0 + 4u * ((STG) * STG_F) + 1024u * (wv * AI + u)), "v"(ga[u]) : "memory");                         \
     _Pragma("unroll") for (int u = 0; u < BI; ++u)                                                                             \
-      if (PQLK_PROBE_DMA_B)                                                                                                    \
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"                                           \
                    ::"s"(lds0 + 4u * ((STG) * STG_F + SA_F) + 1024u * (wv * BI + u)), "v"(gb[u]) : "memory");                   \
     ++issued;                                                                                                                  \
@@ -402,12 +365,15 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
       PQLK_DMA(0);
       PQLK_DMA(1);
       PQLK_DMA(2);
-      if (p.frag_ahead) {
+      if constexpr (MODE == MODE_DX) {
         // ---- fragments one STAGE ahead.  In the loop below a wave reads a stage's operand fragments right behind the barrier that
         // publishes the stage and its first MFMA waits out the LDS latency; the co-resident block is often at the same point.  Here
         // the counted wait is one tile tighter (tile kt + 1 has landed at the top of iteration kt: two tiles of lead instead of
         // three), so the 32 registers of tile kt + 1's fragments are filled WHILE tile kt's 32 MFMAs issue, into a second register
         // set (the kernel used 166 of its 256 VGPRs); behind each barrier the MFMAs start at once.  Same k order: same bits.
+        // dX products only (k-contiguous dY fragments: four ds_read_b128 + sixteen ds_read_b32 per stage): backward of the twin
+        // critic 270.3 -> 262.9 us; the dW products (both operands reduction-row: 32 ds_read2st64_b32 per stage) ran 2 % SLOWER
+        // with it and keep the loop below (tools/kbench.py, interleaved rounds on one box, round 3).
         float fa0[KT / 8][MI][4], fb0[KT / 8][NJ][4], fa1[KT / 8][MI][4], fb1[KT / 8][NJ][4];
 #define PQLK_LDF(STG, FA, FB)                                                                                                  \
   do {                                                                                                                         \
@@ -438,6 +404,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
         dbacc += sa_[row * A_RLD + ((tid % BM) ^ (((row >> 2) & 1) * 32))];                                                    \
       }                                                                                                                        \
     }                                                                                                                          \
+    if (live)                                                                                                                  \
     _Pragma("unroll") for (int k8 = 0; k8 < KT / 8; ++k8)                                                                      \
       _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                                            \
         _Pragma("unroll") for (int i = 0; i < MI; ++i)                                                                         \
@@ -455,12 +422,13 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
         }
 #undef PQLK_LDF
 #undef PQLK_MMF
-      } else
-      for (int kt = 0; kt < nk; kt += 4) {
-        PQLK_DMA_WAIT(2 * NI); __syncthreads(); PQLK_DMA(3); compute(kt, 0);
-        PQLK_DMA_WAIT(2 * NI); __syncthreads(); PQLK_DMA(0); compute(kt + 1, 1);
-        PQLK_DMA_WAIT(2 * NI); __syncthreads(); PQLK_DMA(1); compute(kt + 2, 2);
-        PQLK_DMA_WAIT(2 * NI); __syncthreads(); PQLK_DMA(2); compute(kt + 3, 3);
+      } else {
+        for (int kt = 0; kt < nk; kt += 4) {
+          PQLK_DMA_WAIT(2 * NI); __syncthreads(); PQLK_DMA(3); compute(kt, 0);
+          PQLK_DMA_WAIT(2 * NI); __syncthreads(); PQLK_DMA(0); compute(kt + 1, 1);
+          PQLK_DMA_WAIT(2 * NI); __syncthreads(); PQLK_DMA(1); compute(kt + 2, 2);
+          PQLK_DMA_WAIT(2 * NI); __syncthreads(); PQLK_DMA(2); compute(kt + 3, 3);
+        }
       }
       PQLK_DMA_WAIT(0);
       __syncthreads();   // the tail's re-requests have landed and every wave is done reading: LDS is free for the epilogue
@@ -468,7 +436,6 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
 #undef PQLK_DMA_WAIT
       continue;
     }
-#if !defined(PQLK_PROBE_NOLOAD) && !defined(PQLK_NO_PF2)
     // ---- interior blocks: every tile is full, so the loads need no bounds tests, are straight-line code, and can run TWO
     // tiles ahead: tile kt+2 is requested at the top of iteration kt into the register set that tile kt vacated, tile kt+1
     // (requested one iteration earlier) is moved to LDS at the bottom behind a counted wait.  With one tile of lead
@@ -500,41 +467,22 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
       PQLK_SS(0, 0);
       PQLK_GL(1, 1);
       __syncthreads();
-#if defined(PQLK_PROBE_NOBAR)   // tuning probes only (wrong results): the k loop without its barriers / global requests / LDS stores
-#define PQLK_BAR() __builtin_amdgcn_sched_barrier(0)
-#else
-#define PQLK_BAR() __syncthreads()
-#endif
-#if defined(PQLK_PROBE_NOGL)
-#define PQLK_GLP(KTILE, Q) (void)0
-#else
-#define PQLK_GLP(KTILE, Q) PQLK_GL(KTILE, Q)
-#endif
-#if defined(PQLK_PROBE_NOSS)
-#define PQLK_SSP(STG, Q) (void)0
-#else
-#define PQLK_SSP(STG, Q) PQLK_SS(STG, Q)
-#endif
       for (int kt = 0; kt < nk; kt += 2) {
-        PQLK_GLP(min(kt + 2, nk - 1), 0);
+        PQLK_GL(min(kt + 2, nk - 1), 0);
         __builtin_amdgcn_sched_barrier(0);   // keep the requests at the top of the iteration
         compute(kt, 0);
-        PQLK_SSP(1, 1);
-        PQLK_BAR();
-        PQLK_GLP(min(kt + 3, nk - 1), 1);
+        PQLK_SS(1, 1);
+        __syncthreads();
+        PQLK_GL(min(kt + 3, nk - 1), 1);
         __builtin_amdgcn_sched_barrier(0);
         compute(kt + 1, 1);
-        PQLK_SSP(0, 0);
-        PQLK_BAR();
+        PQLK_SS(0, 0);
+        __syncthreads();
       }
-#undef PQLK_BAR
-#undef PQLK_GLP
-#undef PQLK_SSP
 #undef PQLK_GL
 #undef PQLK_SS
       continue;
     }
-#endif
 
     // ---- generic path (edge tiles): bounds-tested loads, one tile of lead
     KcTile<BM, KT> a_kc;
@@ -576,17 +524,11 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
     __syncthreads();
 
     for (int kt = 0; kt < nk; ++kt) {
-#if defined(PQLK_PROBE_NOLOAD)   // tuning probe only: recompute on stage 0, no global/LDS-store/barrier traffic
-      const int stage = 0;
-#else
       const int stage = kt & 1;
       if (kt + 1 < nk) gload(kt + 1);
-#endif
       compute(kt, stage);
-#if !defined(PQLK_PROBE_NOLOAD)
       if (kt + 1 < nk) sstore(stage ^ 1);
       __syncthreads();
-#endif
     }
   }
 
@@ -638,14 +580,12 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
           const long long grow = m0 + wm + 32 * i + rr;
           const int gcol = n0 + wn + 4 * pc4;
           if (EPI == EPI_DELU) {
-            float4 h4;
-            if (AUX_PF && !p.frag_ahead) {
-              h4 = make_float4(hpre[i][it].x, hpre[i][it].y, hpre[i][it].z, hpre[i][it].w);
-            } else {
-              long long arow = grow;
-              if (MODE == MODE_DX && p.perm) { const int pr = p.perm[grow]; arow = pr < 0 ? 0 : pr; }   // pad rows: dZ is zero anyway
-              h4 = *reinterpret_cast<const float4*>(auxw + arow * p.ldaux + gcol);
-            }
+            // (round 2 requested this operand before the k loop into 64 spare registers; round 3 gave those registers to the
+            //  second fragment set of the stage-ahead loop, which measured better: backward 270.3 -> 262.9 us; both together
+            //  spill the prefetch to scratch and measured worse again, 273.1 -> 276.7)
+            long long arow = grow;
+            if (MODE == MODE_DX && p.perm) { const int pr = p.perm[grow]; arow = pr < 0 ? 0 : pr; }   // pad rows: dZ is zero anyway
+            const float4 h4 = *reinterpret_cast<const float4*>(auxw + arow * p.ldaux + gcol);
             v.x = h4.x > 0.f ? v.x : v.x * (h4.x + 1.f);  // ELU'(x) = exp(x) = elu(x) + 1 for x <= 0
             v.y = h4.y > 0.f ? v.y : v.y * (h4.y + 1.f);
             v.z = h4.z > 0.f ? v.z : v.z * (h4.z + 1.f);
@@ -719,11 +659,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
             v[2] = h4.z > 0.f ? v[2] : v[2] * (h4.z + 1.f);
             v[3] = h4.w > 0.f ? v[3] : v[3] * (h4.w + 1.f);
           }
-#if defined(PQLK_PROBE_NOSTORE)   // tuning probe only: keep the values live, skip the HBM write
-          asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-#else
           *reinterpret_cast<float4*>(C + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
-#endif
           continue;
         }
         if (row >= p.M) continue;
@@ -797,19 +733,18 @@ static bool gemm_plan(GemmP& p, int gz, dim3& grid) {
   grid = dim3((unsigned)((ncols + BN - 1) / BN), (unsigned)((p.M + BM - 1) / BM), (unsigned)gz);
   {
     const long long tiles = (long long)grid.x * grid.y * grid.z, group = (MODE == MODE_DW) ? (long long)grid.x * grid.y : grid.x;
-    p.xcd_remap = gemm_xcd_enabled() && tiles % (8 * group) == 0 && tiles < (1LL << 30);
+    p.xcd_remap = 0;
+    if (gemm_xcd_enabled() && tiles < (1LL << 30)) {
+      if (tiles % (8 * group) == 0) p.xcd_remap = 1;                       // whole groups of operand-sharing tiles per XCD
+      else if (tiles >= 64) p.xcd_remap = (int)tiles;                      // contiguous runs (see gemm_body)
+    }
   }
-  p.frag_ahead = 0;
   if constexpr (KT == 16 && (MODE == MODE_DX || MODE == MODE_DW) && (EPI == EPI_DELU || EPI == EPI_NONE)) {
     bool dma = gemm_dma_enabled() && p.M % BM == 0 && ncols % BN == 0 && p.N % BN == 0 && !p.C2 && pqlk_aligned16(p.A) &&
                pqlk_aligned16(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0 && (EPI != EPI_DELU || (p.aux && pqlk_aligned16(p.aux) && p.ldaux % 4 == 0));
     if (MODE == MODE_DX) dma = dma && p.K % (4 * KT) == 0 && p.K <= p.lda && ncols <= p.ldb && p.sA % 4 == 0 && p.sB % 4 == 0;
     else dma = dma && p.rows_per_split % (4 * KT) == 0 && p.K % p.rows_per_split == 0 && p.K / p.rows_per_split == p.splits &&
                p.M <= p.lda && p.N <= p.ldb && p.sA % 4 == 0 && p.sB % 4 == 0;
-    // fragments a stage ahead: dX products only (k-contiguous dY fragments: four ds_read_b128 + sixteen ds_read_b32 per stage):
-    // backward of the twin critic 270.3 -> 262.9 us; the dW products (both operands reduction-row: 32 ds_read2st64_b32 per
-    // stage) ran 2 % SLOWER with it (tools/kbench.py, interleaved rounds on one box, round 3)
-    if (dma) p.frag_ahead = (MODE == MODE_DX && !g_pqlk_knob[1]) ? 1 : 0;
     return dma;
   }
   return false;
@@ -860,14 +795,12 @@ template <int MODE, int EPI>
 static int launch_tile(const GemmP& p, int gz, hipStream_t st) {
   const int ncols = (MODE == MODE_DW) ? p.N : p.ncols_store;
   const long long big = (long long)((p.M + 127) / 128) * ((ncols + 127) / 128) * gz;
-#if !defined(PQLK_FORCE_TILE64)   // tuning switch: everything on 64x64 tiles (more, smaller, better-interleaving blocks)
   // (128 x 64 tiles at three blocks per CU for the dense products: dX the same, dW 1-2 % slower -- measured, not used)
   // (the same tiles for launches of exactly one 128 x 128 tile per CU, so that no block sits alone on its CU: neutral to -1 % with
   //  the LDS-DMA loop -- a lone block there already keeps three tiles in flight)
   if (big >= 256 && ncols >= 128 && EPI != EPI_DTANH_SLICE) return launch_gemm<MODE, 128, 128, EPI>(p, gz, st);
   // (128 x 64 dW tiles for the products that 128 x 128 tiles leave at under one block per CU -- layer 1 of the critic, the actor's
   //  256-row layer: V step 617.5 -> 618.9 us, P step 542.8 -> 543.7: not used; round 3)
-#endif
   return launch_gemm<MODE, 64, 64, EPI>(p, gz, st);
 }
 
@@ -1040,10 +973,6 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
   int buf_ld = 0;
   if (!fusable(d, &buf_ld)) return PQLK_E_UNSUPPORTED;
   p.X = x; p.params = params; p.packed = packed; p.acts = acts;
-#if defined(PQLK_FP_CLK)
-  extern long long* g_fp_clk;
-  p.clk = g_fp_clk;
-#endif
   p.B = (int)b; p.ldx = (int)ldx; p.n_hidden = d->n_layers - 1; p.stash_all = stash_all; p.buf_ld = buf_ld; p.n_nets = d->n_nets;
   p.net_stride = pqlk_mlp_net_stride(d); p.packed_net_stride = packed_net_stride(d);
   int64_t p_off = 0;

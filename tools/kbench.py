@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of the V-learner's launches on one MI355X (HIP events over hipGraphs of repeated launches).
 
-    python tools/kbench.py [--variants "base;0=1;1=1"] [--rounds 5] [--sections fwd,bwd,opt,step] [bench.py flags ...]
+    python tools/kbench.py [--variants "base;td=0;rng=torch"] [--rounds 5] [--sections actor,target,critic,bwd,opt,vstep,pstep] [bench.py flags ...]
 
-A variant is a comma-separated list of `knob=value` settings of libpqlk's experiment switches (pqlk_debug_knob) or of
-learner attributes (`td=0|1`).  Every section is timed for every variant in every round (cdna_hip_programming.md rule 24:
-deltas come from interleaved rounds in ONE process); the table prints median and min per (section, variant).  GPU only."""
+A variant is a comma-separated list of learner settings (`td=0|1`: TD loss inside the head backward or as its own launch;
+`rng=auto|torch`: draws ahead + batched gather or per-step ATen draws; `env:NAME=value`: an environment switch the library reads
+per call).  Every section is timed for every variant in every round (cdna_hip_programming.md rule 24: deltas come from
+interleaved rounds in ONE process); the table prints median and min per (section, variant).  Kernel-level experiments of a tuning
+round are built as a second variant behind a temporary switch and compared here; the switch goes once a variant is chosen
+(round 3: DESIGN.md section 11).  GPU only."""
 import argparse
 import ctypes as C
 import os
@@ -69,16 +72,21 @@ def main():
     torch.cuda.synchronize()
 
     def apply(variant):
-        for k in range(16):
-            L.lib.pqlk_debug_knob(k, 0)
         v._td_in_head = True
+        v._rng_mode = p._rng_mode = "auto"
+        for k in [k for k in os.environ if k.startswith("PQLK_AB_")]:
+            del os.environ[k]
         if variant != "base":
             for kv in variant.split(","):
                 k, val = kv.split("=")
                 if k == "td":
                     v._td_in_head = bool(int(val))
+                elif k == "rng":
+                    v._rng_mode = p._rng_mode = val
+                elif k.startswith("env:"):
+                    os.environ["PQLK_AB_" + k[4:]] = val
                 else:
-                    L.lib.pqlk_debug_knob(int(k), int(val))
+                    raise SystemExit(f"unknown variant key {k!r}")
         v._ws = None
         v._graph = None
         p._ws = None
