@@ -673,7 +673,9 @@ def main():
         alg_bytes = K * per_batch
         line["roofline_gather"] = {"bound": "hbm", "kernel": "k_replay_gather_fused", "achieved": alg_bytes / (gms * 1e-3) / 1e9,
                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_bytes / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                   "traffic": traffic.get("gather_per_launch_bytes") if K == 1 else None, "algorithmic_bytes": alg_bytes,
+                                   "traffic": traffic.get("gather_per_launch_bytes") if traffic.get("gather_batches_per_launch", 1) == K else None,
+                                   "traffic_source": (f"committed profile {traffic_src}, NOT measured in this run") if traffic_src else None,
+                                   "algorithmic_bytes": alg_bytes,
                                    "us_per_launch": gms * 1e3, "batches_per_launch": K, "rows_per_launch": K * args.batch,
                                    "us_per_batch": gms * 1e3 / K, "record_bytes": rec_ld * 4}
         if K > 1:   # the per-step launch (algo.rng=torch, injected draws) for comparison

@@ -38,6 +38,10 @@ CASES = {
     "free-running, distributional, eager": ["task=AllegroHand", "algo.async_learners=True", "algo.distl=True", "algo.graph=False"],
     "batch not a multiple of 128": ["task=AllegroHand", "algo.batch_size=1000"],
     "tiny (64 envs, batch 256)": ["task=AllegroHand", "num_envs=64", "algo.batch_size=256", "max_step=40000"],
+    "per-step ATen draws (rng=torch)": ["task=AllegroHand", "algo.rng=torch"],
+    "draws 3 steps ahead (not a divisor of 8)": ["task=AllegroHand", "algo.prefetch_steps=3", "algo.prefetch_steps_p=5"],
+    "free-running, draws ahead, TD loss as its own launch": ["task=AllegroHand", "algo.async_learners=True", "algo.td_in_head=False"],
+    "SAC-style ratios 1:1:4": ["task=AllegroHand", "algo.critic_sample_ratio=4", "algo.critic_actor_ratio=1"],
 }
 
 

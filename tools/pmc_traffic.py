@@ -1,12 +1,14 @@
 """Builds profiles/<tag>_pmc_traffic.json from two `rocprofv3 --kernel-trace --pmc ...` passes over
 
-    python bench.py --steps 48 --warmup 16 --no-cpu-baseline --no-streams --v-only
+    python bench.py --steps 48 --warmup 16 --no-cpu-baseline --no-streams --v-only --burn-in-ms 0 --no-roofline
 
 (FETCH_SIZE in one pass, WRITE_SIZE in the other: together they do not fit the TCC counter slots).  Units and the gfx950
 correction follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): both counters are in KiB at the L2 <-> fabric boundary,
 FETCH_SIZE reports half the bytes of wide coalesced reads and is doubled here, WRITE_SIZE is taken as is.
 
-    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>
+    python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [batches per gather launch = 8]
+
+The replay gather in that trace is the launch that serves the next 8 V-learner steps at once (PQLVLearner._prefetch, algo.rng=auto).
 """
 import collections
 import csv
@@ -35,12 +37,13 @@ def family(tot, calls, keys):
 
 def main():
     fetch_csv, write_csv, out = sys.argv[1:4]
+    batches = int(sys.argv[4]) if len(sys.argv) > 4 else 8
     ft, fc = per_kernel(fetch_csv, "FETCH_SIZE")
     wt, wc = per_kernel(write_csv, "WRITE_SIZE")
-    # MFMA launch groups in the trace: every V step AND every repetition of bench.py's roofline section runs the three
-    # fused forwards (target actor, target critic, critic) + one critic backward, whose Q-head pass `k_skinny_bwd<1, ...>` no
-    # other component launches (the rollout's policy forward of set-up is a fused launch too, so fused launches / 3 no longer
-    # counts groups; its ~40 launches of 4096 rows stay in the family total: < 1 % of it)
+    # MFMA launch groups in the trace = V steps (warm-up, timed and the graph captures' dry runs): each runs the three fused
+    # forwards (target actor, target critic, critic) + one critic backward, whose Q-head pass `k_skinny_bwd<1, ...>` no other
+    # component launches (the rollout's policy forward of set-up is a fused launch too; its ~40 launches of 4096 rows stay in the
+    # family total: < 1 % of it)
     def groups(calls):
         n = sum(c for k, c in calls.items() if "k_skinny_bwd<1," in k)
         assert n, "no Q-head backward launch in the trace"
@@ -52,7 +55,7 @@ def main():
     g_w, g_wc = family(wt, wc, GATHER)
     res = {
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --steps 48 --warmup 16 "
-                  "--no-cpu-baseline --no-streams --v-only",
+                  "--no-cpu-baseline --no-streams --v-only --burn-in-ms 0 --no-roofline",
         "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced reads); counters sit at "
                 "the L2 <-> fabric boundary, Infinity-Cache hits included",
         "mfma_launch_groups_in_trace": [v_steps_f, v_steps_w],
@@ -62,6 +65,8 @@ def main():
         "gather_fetch_raw_kb": g_f / g_fc,
         "gather_write_kb": g_w / g_wc,
         "gather_per_launch_bytes": (2.0 * g_f / g_fc + g_w / g_wc) * 1024.0,
+        "gather_batches_per_launch": batches,
+        "gather_launches_in_trace": [g_fc, g_wc],
     }
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))

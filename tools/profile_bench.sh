@@ -25,7 +25,7 @@ run() {   # name, bench flags...
 pmc() {   # counter name
   local c=$1
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python3 bench.py --steps 48 --warmup 16 \
-      --no-cpu-baseline --no-streams --v-only --repeat 1 > /dev/null 2> $OUT/pmc_$c.err || { tail -5 $OUT/pmc_$c.err; return 1; }
+      --no-cpu-baseline --no-streams --v-only --repeat 1 --burn-in-ms 0 --no-roofline > /dev/null 2> $OUT/pmc_$c.err || { tail -5 $OUT/pmc_$c.err; return 1; }
   find $OUT/pmc_$c -name "*counter_collection.csv" | head -1
 }
 run sched --steps 400 --warmup 48
@@ -37,7 +37,7 @@ if [ "$2" = "full" ]; then
   rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
   # matrix-pipe utilisation per kernel (a third counter pass, kernel-trace only)
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o pmc -- python3 bench.py \
-      --steps 48 --warmup 16 --no-cpu-baseline --no-streams --v-only --repeat 1 > /dev/null 2> $OUT/pmc_mfma.err || tail -5 $OUT/pmc_mfma.err
+      --steps 48 --warmup 16 --no-cpu-baseline --no-streams --v-only --repeat 1 --burn-in-ms 0 --no-roofline > /dev/null 2> $OUT/pmc_mfma.err || tail -5 $OUT/pmc_mfma.err
   python3 tools/pmc_mfma.py "$(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1)" $OUT/pmc_mfma.json > /dev/null
   rm -rf $OUT/pmc_mfma
   python3 bench.py --steps 800 --warmup 96 > $OUT/bench.json 2> $OUT/bench.err
@@ -48,5 +48,16 @@ if [ "$2" = "full" ]; then
   python3 bench.py --no-cpu-baseline --task Humanoid --batch 32768 --nstep 5 --replay 5000000 --steps 200 > $OUT/bench_cfg5_hidden512x512x256.json 2>/dev/null
   python3 bench.py --no-cpu-baseline --gpus 2 --layout split2 --share-gpu > $OUT/bench_split2_one_card.json 2>/dev/null
   python3 bench.py --no-cpu-baseline --gpus 2 --backend gloo --share-gpu --steps 100 2>/dev/null | grep "^{" > $OUT/bench_dp2_gloo_one_card.json
-  python3 tools/bench_gather.py cfg2 cfg5 cfg4 > $OUT/gather_sweep.log 2>&1
+  python3 bench.py --no-cpu-baseline --gpus 2 --backend gloo --share-gpu --steps 100 --scaling strong 2>/dev/null | grep "^{" > $OUT/bench_dp2_strong_gloo_one_card.json
+  PQL_FORCE_DP=1 python3 bench.py --no-cpu-baseline > $OUT/bench_dp1_rccl_one_rank.json 2>/dev/null
+  python3 tools/bench_gather.py cfg2 cfg2x8 cfg5x8 cfg4x8 > $OUT/gather_sweep.log 2>&1
+  # per-launch timelines of one steady-state V / P step (device clock)
+  for m in v p; do
+    rocprofv3 --kernel-trace --output-format csv -d $OUT/tl_$m -o tl -- python3 bench.py --$m-only --no-streams --steps 40 --warmup 8 --repeat 1 \
+        --burn-in-ms 0 --no-roofline --no-cpu-baseline > /dev/null 2> $OUT/tl_$m.err
+    python3 tools/step_timeline.py $OUT/tl_$m k_adamw > $OUT/${m}_step_timeline.txt
+    rm -rf $OUT/tl_$m
+  done
+  python3 bench.py --no-cpu-baseline --rng torch > $OUT/bench_rng_torch.json 2>/dev/null
+  python3 tools/roofline_from_stats.py $OUT/v_only_kernel_stats.csv > $OUT/v_only_roofline.md
 fi
