@@ -49,7 +49,7 @@ if [ "$2" = "full" ]; then
   python3 bench.py --no-cpu-baseline --gpus 2 --layout split2 --share-gpu > $OUT/bench_split2_one_card.json 2>/dev/null
   python3 bench.py --no-cpu-baseline --gpus 2 --backend gloo --share-gpu --steps 100 2>/dev/null | grep "^{" > $OUT/bench_dp2_gloo_one_card.json
   python3 bench.py --no-cpu-baseline --gpus 2 --backend gloo --share-gpu --steps 100 --scaling strong 2>/dev/null | grep "^{" > $OUT/bench_dp2_strong_gloo_one_card.json
-  PQL_FORCE_DP=1 python3 bench.py --no-cpu-baseline > $OUT/bench_dp1_rccl_one_rank.json 2>/dev/null
+  PQL_FORCE_DP=1 python3 bench.py --no-cpu-baseline 2>/dev/null | grep "^{" > $OUT/bench_dp1_rccl_one_rank.json   # (RCCL prints a version banner on stdout)
   python3 tools/bench_gather.py cfg2 cfg2x8 cfg5x8 cfg4x8 > $OUT/gather_sweep.log 2>&1
   # per-launch timelines of one steady-state V / P step (device clock)
   for m in v p; do
