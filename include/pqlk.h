@@ -192,14 +192,6 @@ int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const float* pack
                      int32_t out_act, const float* draw, float noise_std, float noise_clip,
                      float* acts, float* out2, int64_t ld_out2, pqlk_stream_t stream);
 
-/* Two forwards of the same layout over the same number of rows (same ldx) in ONE launch -- the target critic and the critic of
- * a V-learner step (pql_v_learner.py:79-104): linear outputs (PQLK_ACT_NONE), each problem with its own parameters, packed
- * copy, input, stash flag and activation stash.  Bit-identical to two pqlk_mlp_forward calls, which is also what it falls back
- * to when the layout cannot take the fused path. */
-int pqlk_mlp_forward_pair(const PqlMlpDesc* d, int64_t ldx, int64_t b, const float* params_a, const float* packed_a,
-                          int32_t stash_all_a, const float* x_a, float* acts_a, const float* params_b, const float* packed_b,
-                          int32_t stash_all_b, const float* x_b, float* acts_b, pqlk_stream_t stream);
-
 /* Backward.  dy: (n_nets, B, pqlk_ld(out)) gradient w.r.t. the last layer's PRE-activation output
  * (loss kernels below produce exactly that).  grads (arena layout) is overwritten with the full
  * parameter gradient when != NULL (deterministic split-batch partial sums through `ws`).

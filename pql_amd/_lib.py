@@ -53,7 +53,6 @@ PROTOTYPES = {
     "pqlk_mlp_forward": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I32, _P, _I64, _I64, _I32, _P, _F, _F, _P, _P, _I64, _P]),
     "pqlk_mlp_backward": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _P, _I64,
                                     _P, _I64, _P]),
-    "pqlk_mlp_forward_pair": (C.c_int, [C.POINTER(PqlMlpDesc), _I64, _I64, _P, _P, _I32, _P, _P, _P, _P, _I32, _P, _P, _P]),
     "pqlk_mlp_backward_norm": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _P, _I32, _P, _I64, _I32, _I32, _P, _I64,
                                          _P, _I64, _P, _P, _P]),
     "pqlk_mlp_norm_parts": (_I32, [C.POINTER(PqlMlpDesc)]),

@@ -262,7 +262,6 @@ class PQLVLearner:
         # Philox offset through two 1-element fill launches per replay (~9 us of device time per step, more than the draws save
         # by being captured), and the graph no longer bakes in the randint bound, so it is not re-captured while the ring fills.
         self._graph_rng = bool(_cfg_get(algo, "graph_rng", False))
-        self._pair_forward = bool(_cfg_get(algo, "pair_forward", False))
         # own HIP stream: the MI355X form of the reference's separate learner process (Ray actor).  V-learner,
         # P-learner and rollout queues then overlap on the GPU; hand-offs are event-fenced in update().
         self.stream = torch.cuda.Stream(self.device) if bool(_cfg_get(algo, "streams", False)) else None
@@ -433,21 +432,10 @@ class PQLVLearner:
         xn_act = ws["xn_sa"][:, O:]
         mlp_forward_raw(al, self.actor.arena.data, ws["xn_sa"] if actor_in_sa else ws["xn_obs"], L.ACT_TANH_NOISE, draw, algo.noise.tgt_pol_std,
                         algo.noise.tgt_pol_noise_bound, ws["acts_a"], xn_act, packed=self.pk_actor, stash_all=False)
-        if (self._pair_forward and self._fused and self.pk_target.tensor is not None and self.pk_critic.tensor is not None
-                and ws["ld_sa"] == cl.ld_in):
-            # `algo.pair_forward` (off by default): target critic (no stash) and critic (stashing) as ONE launch of 4 x tiles
-            # blocks (same bits).  Measured: V alone +0.3 %, but the 1:2:8 schedule -1 % (1128-1134 against 1140-1144, three
-            # alternating runs on one box): a single 260-us launch at one block per CU leaves the P-learner's and the
-            # rollout's kernels nothing to interleave with.
-            L.check(L.lib.pqlk_mlp_forward_pair(C.byref(cl.desc), ws["ld_sa"], B, L.ptr(self.critic_target.arena.data),
-                                                L.ptr(self.pk_target.tensor), 0, L.ptr(ws["xn_sa"]), L.ptr(ws["acts_t"]),
-                                                L.ptr(self.critic.arena.data), L.ptr(self.pk_critic.tensor), 1, L.ptr(ws["x_sa"]),
-                                                L.ptr(ws["acts_c"]), st))
-        else:
-            mlp_forward_raw(cl, self.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"], packed=self.pk_target,
-                            stash_all=False)
-            mlp_forward_raw(cl, self.critic.arena.data, ws["x_sa"], L.ACT_NONE, acts=ws["acts_c"], packed=self.pk_critic,
-                            stash_all=True)
+        mlp_forward_raw(cl, self.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"], packed=self.pk_target,
+                        stash_all=False)
+        mlp_forward_raw(cl, self.critic.arena.data, ws["x_sa"], L.ACT_NONE, acts=ws["acts_c"], packed=self.pk_critic,
+                        stash_all=True)
         q = output_view(cl, ws["acts_c"], B)
         qt = output_view(cl, ws["acts_t"], B)
         gamma_n = float(algo.gamma) ** int(algo.nstep)

@@ -34,10 +34,6 @@ struct FusedP {
   const float* params;  // parameter arena (biases are read from here)
   const float* packed;  // fragment-ordered hidden-layer weights
   float* acts;          // activation stash (layout of pqlk_mlp_act_offset)
-  // pair != 0: a SECOND problem of the same layout and batch rides in the same launch (pqlk_mlp_forward_pair: the target critic
-  // and the critic of a V-learner step): 2 x the blocks, XCDs 0-3 take problem one, 4-7 problem two
-  const float* X2; const float* params2; const float* packed2; float* acts2;
-  int pair, stash_all2;
   int B, ldx, n_hidden, stash_all, buf_ld, n_nets;
   int dims[PQLK_MAX_LAYERS + 1];  // in (logical), h1, h2, ...
   long long net_stride, packed_net_stride;
@@ -283,14 +279,8 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
   // XCD the weight stream thrashes L2 and falls back to the Infinity Cache.  Even XCD groups take net 0, odd ones
   // net 1, so each L2 keeps ONE net's weights resident.  (Speed only: any placement computes the same result.)
   int net, tile;
-  bool second = false;
   const int tiles = (p.B + 32 * R - 1) / (32 * R);
-  if (p.pair) {   // (host side: n_nets == 2, tiles even) one (problem, net) weight set per XCD
-    const int b = blockIdx.x, g = b & 7, i = b >> 3;
-    second = g >= 4;
-    net = g & 1;
-    tile = i * 2 + ((g >> 1) & 1);
-  } else if (p.n_nets == 2 && (tiles & 3) == 0) {
+  if (p.n_nets == 2 && (tiles & 3) == 0) {
     const int b = blockIdx.x, g = b & 7, i = b >> 3;
     net = g & 1;
     tile = i * 4 + (g >> 1);
@@ -298,11 +288,11 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
     net = blockIdx.x / tiles;
     tile = blockIdx.x % tiles;
   }
-  const float* __restrict__ pX = second ? p.X2 : p.X;
-  const float* __restrict__ pparams = second ? p.params2 : p.params;
-  const float* __restrict__ ppacked = second ? p.packed2 : p.packed;
-  float* __restrict__ pacts = second ? p.acts2 : p.acts;
-  const int pstash = second ? p.stash_all2 : p.stash_all;
+  const float* __restrict__ pX = p.X;
+  const float* __restrict__ pparams = p.params;
+  const float* __restrict__ ppacked = p.packed;
+  float* __restrict__ pacts = p.acts;
+  const int pstash = p.stash_all;
   const int row0 = tile * 32 * R;
   const bool full_tile = row0 + 32 * R <= p.B;
   const int buf_ld4 = p.buf_ld >> 2;

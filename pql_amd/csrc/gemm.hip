@@ -962,13 +962,8 @@ static bool head_fusable(const PqlMlpDesc* d) {
   return d->n_layers >= 2 && d->dims[d->n_layers] <= 32 && d->dims[d->n_layers - 1] % 32 == 0;
 }
 
-struct FusedSecond {   // the second problem of a paired launch (same layout, batch and leading dimension)
-  const float* params; const float* packed; const float* x; float* acts; int stash_all;
-};
-
 static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const float* packed, const float* x, int64_t ldx,
-                               int64_t b, float* acts, int stash_all, hipStream_t st, const FusedHead* head = nullptr,
-                               const FusedSecond* second = nullptr) {
+                               int64_t b, float* acts, int stash_all, hipStream_t st, const FusedHead* head = nullptr) {
   FusedP p = {};
   int buf_ld = 0;
   if (!fusable(d, &buf_ld)) return PQLK_E_UNSUPPORTED;
@@ -1018,51 +1013,11 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
   }
   const size_t shmem = fused_lds_bytes(d, buf_ld, R);
   dim3 grid((unsigned)(((b + 32 * R - 1) / (32 * R)) * d->n_nets)), block(64 * FUSED_NW);
-  if (second) {
-    if (d->n_nets != 2 || ((b + 32 * R - 1) / (32 * R)) % 2 != 0) return PQLK_E_UNSUPPORTED;   // the caller then launches twice
-    p.pair = 1; p.X2 = second->x; p.params2 = second->params; p.packed2 = second->packed; p.acts2 = second->acts;
-    p.stash_all2 = second->stash_all;
-    grid.x *= 2;
-  }
   if (wide) hipLaunchKernelGGL((k_mlp_fwd_fused<1, 4>), grid, block, shmem, st, p);
   else if (R == 2) hipLaunchKernelGGL((k_mlp_fwd_fused<2, 2>), grid, block, shmem, st, p);
   else hipLaunchKernelGGL((k_mlp_fwd_fused<1, 2>), grid, block, shmem, st, p);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
-}
-
-// ================================================================================================
-// Two forwards of the SAME layout over the same number of rows in one launch (the target critic and the critic of a V-learner
-// step, pql_v_learner.py:79-104: different weights, different inputs, no dependence on each other): 4 x tiles blocks instead of
-// two launches of 2 x tiles, so the second problem's blocks start as CUs come free instead of behind the first launch's slowest
-// block.  Per-block arithmetic unchanged: same bits as two pqlk_mlp_forward calls.  Linear outputs only (ACT_NONE); falls back
-// to two launches when the layout cannot take the fused path.
-extern "C" int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const float* packed, int32_t stash_all, const float* x,
-                                int64_t ldx, int64_t b, int32_t out_act, const float* draw, float noise_std, float noise_clip,
-                                float* acts, float* out2, int64_t ld_out2, pqlk_stream_t stream);
-
-extern "C" int pqlk_mlp_forward_pair(const PqlMlpDesc* d, int64_t ldx, int64_t b, const float* params_a, const float* packed_a,
-                                     int32_t stash_all_a, const float* x_a, float* acts_a, const float* params_b,
-                                     const float* packed_b, int32_t stash_all_b, const float* x_b, float* acts_b,
-                                     pqlk_stream_t stream) {
-  int rc = desc_ok(d);
-  if (rc) return rc;
-  PQLK_REQUIRE(params_a && x_a && acts_a && params_b && x_b && acts_b, PQLK_E_NULL);
-  if (packed_a && packed_b && fusable(d, nullptr) && head_fusable(d) && d->n_nets == 2 && getenv("PQLK_NO_FUSED_HEAD") == nullptr &&
-      getenv("PQLK_NO_PAIR") == nullptr) {
-    PQLK_REQUIRE(b > 0 && b < (1LL << 30), PQLK_E_SHAPE);
-    PQLK_REQUIRE(ldx % 32 == 0 && ldx >= pqlk_ld(d->dims[0]), PQLK_E_ALIGN);
-    PQLK_REQUIRE(pqlk_aligned16(params_a) && pqlk_aligned16(x_a) && pqlk_aligned16(acts_a) && pqlk_aligned16(packed_a) &&
-                 pqlk_aligned16(params_b) && pqlk_aligned16(x_b) && pqlk_aligned16(acts_b) && pqlk_aligned16(packed_b), PQLK_E_ALIGN);
-    FusedHead head = {};
-    head.n = d->dims[d->n_layers]; head.epi = PQLK_ACT_NONE;
-    const FusedSecond sec = {params_b, packed_b, x_b, acts_b, stash_all_b ? 1 : 0};
-    rc = launch_fused_hidden(d, params_a, packed_a, x_a, ldx, b, acts_a, stash_all_a ? 1 : 0, pqlk_s(stream), &head, &sec);
-    if (rc != PQLK_E_UNSUPPORTED) return rc;
-  }
-  rc = pqlk_mlp_forward(d, params_a, packed_a, stash_all_a, x_a, ldx, b, PQLK_ACT_NONE, nullptr, 0.f, 0.f, acts_a, nullptr, 0, stream);
-  if (rc) return rc;
-  return pqlk_mlp_forward(d, params_b, packed_b, stash_all_b, x_b, ldx, b, PQLK_ACT_NONE, nullptr, 0.f, 0.f, acts_b, nullptr, 0, stream);
 }
 
 extern "C" int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const float* packed, int32_t stash_all,

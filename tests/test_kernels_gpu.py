@@ -934,36 +934,6 @@ def test_rms_merge_normalize_and_action_noise_kernels_match_the_cpu_expressions(
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("dims,B", [([104, 512, 512, 256, 1], 8192), ([232, 512, 256, 128, 51], 2048), ([104, 512, 512, 256, 1], 4096 + 64)])
-def test_paired_forward_is_bitwise_two_forwards(dev, dims, B):
-    """pqlk_mlp_forward_pair (target critic + critic of a V step in one launch) against two pqlk_mlp_forward calls: every
-    stashed activation and both outputs bit for bit, one problem stashing and the other not."""
-    from pql_amd import _lib as L
-    from pql_amd.models.mlp import ArenaLayout, PackedWeights, mlp_forward_raw
-    lay = ArenaLayout(dims, 2)
-    arenas, packs, xs = [], [], []
-    for k in range(2):
-        a = torch.zeros(lay.total, device=dev)
-        for n in range(2):
-            for l in range(lay.n_layers):
-                bound = 1.0 / np.sqrt(dims[l])
-                lay.weight(a, n, l).copy_(T(dd.uniform((dims[l + 1], dims[l]), 500 + 100 * k + 10 * n + l, -bound, bound)))
-                lay.bias(a, n, l).copy_(T(dd.uniform((dims[l + 1],), 550 + 100 * k + 10 * n + l, -bound, bound)))
-        pk = PackedWeights(lay, dev); pk.refresh(a)
-        x = torch.zeros((B, lay.ld_in), device=dev); x[:, : dims[0]] = T(dd.uniform((B, dims[0]), 700 + k, -2, 2)).to(dev)
-        arenas.append(a); packs.append(pk); xs.append(x)
-    want = [mlp_forward_raw(lay, arenas[0], xs[0], L.ACT_NONE, packed=packs[0], stash_all=False),
-            mlp_forward_raw(lay, arenas[1], xs[1], L.ACT_NONE, packed=packs[1], stash_all=True)]
-    got = [torch.full_like(want[0], float("nan")), torch.full_like(want[1], float("nan"))]
-    L.check(L.lib.pqlk_mlp_forward_pair(C.byref(lay.desc), lay.ld_in, B, L.ptr(arenas[0]), L.ptr(packs[0].tensor), 0, L.ptr(xs[0]),
-                                        L.ptr(got[0]), L.ptr(arenas[1]), L.ptr(packs[1].tensor), 1, L.ptr(xs[1]), L.ptr(got[1]),
-                                        L.stream(dev)))
-    torch.cuda.synchronize()
-    off, ld = lay.act_offset(B, 0, lay.n_layers - 1)
-    assert torch.equal(got[0][off:], want[0][off:])      # no stash: only the output block is defined
-    assert torch.equal(got[1], want[1])                  # stash: every activation
-
-
 # --------------------------------------------------------------------------- the learners' draws (SURVEY Appendix B)
 def test_philox_draws_are_torchs_own_numbers(dev):
     """pqlk_philox_draws == the stream of torch calls it replaces, bit for bit: `randint(range, (B,))` then `(B, A).normal_()`
