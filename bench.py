@@ -524,6 +524,15 @@ def main():
             handoff.FORCE_SHIP = True
     torch.cuda.set_device(device)
     pg = None
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner (this image exports NCCL_DEBUG=VERSION) and its
+    # warnings straight to file descriptor 1: from here on fd 1 is stderr, and the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+
     if world > 1 or os.environ.get("PQL_FORCE_DP"):   # PQL_FORCE_DP=1: rehearse the RCCL path with a 1-rank group
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
@@ -631,7 +640,7 @@ def main():
         "gflop_per_v_step": f_v / 1e9, "gflop_per_p_step": f_p / 1e9,
     }
     if rank == 0 and args.no_roofline:
-        print(json.dumps(line), flush=True)
+        emit(line)
     elif rank == 0:
         traffic, traffic_src = {}, None
         import glob
@@ -690,7 +699,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args, O, A, hidden)
             note("cpu baseline done")
             line["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
-        print(json.dumps(line), flush=True)
+        emit(line)
     if pg is not None:
         barrier()   # the other ranks wait here while rank 0 measures its roofline sections
         torch.distributed.destroy_process_group()
