@@ -287,6 +287,22 @@ def test_c_abi_reports_argument_errors_as_codes():
     assert lib.pqlk_adamw_polyak_fused(None, P, P, P, P, P, None, None, 1.0, 0.5, 5e-4, 0.9, 0.999, 1e-8, 1e-2, 0.05, P, None, P, 8,
                                        None, 0, 1.0, None, 0, None) == E_NULL
     assert lib.pqlk_loss_parts(8192, 1) > 0 and lib.pqlk_mlp_norm_parts(C.byref(d)) > 0
+    # round-3 entry points: TD-fused critic backward, Philox draws
+    E_RANGE = 3
+    assert lib.pqlk_mlp_backward_td(C.byref(d), P, P, 32, 4, P, None, P, P, 0.97, P, P, 1, P, 1 << 20, None, None, None) == E_NULL   # target stash
+    assert lib.pqlk_mlp_backward_td(C.byref(d), P, P, 32, 4, P, P, P, P, 0.97, P, P, 1, P, 1 << 20, P, None, None) == E_NULL        # sumsq without step
+    d1 = L.mlp_desc([8, 64, 1], 1)
+    assert lib.pqlk_mlp_backward_td(C.byref(d1), P, P, 32, 4, P, P, P, P, 0.97, P, P, 1, P, 1 << 20, None, None, None) == E_UNSUPPORTED  # one net
+    assert lib.pqlk_td_head_loss_parts(C.byref(d), 8192) == 512 and lib.pqlk_td_head_loss_parts(C.byref(d1), 8192) == 0
+    assert lib.pqlk_td_head_loss_parts(C.byref(L.mlp_desc([8, 64, 51], 2)), 8192) == 0                                    # C51 heads: own loss kernel
+    assert lib.pqlk_philox_draws(1, 0, 0, None, 100, None, 8, None, 0, 1, 1, None) == E_NULL
+    assert lib.pqlk_philox_draws(1, 0, 0, None, 1 << 28, P, 8, None, 0, 1, 1, None) == E_RANGE       # torch draws 64-bit values from 2^28 on
+    assert lib.pqlk_philox_draws(1, 2, 0, None, 100, P, 8, None, 0, 1, 1, None) == E_ALIGN          # offsets advance in whole Philox blocks
+    assert lib.pqlk_philox_draws(1, 0, 0, None, 100, P, 0, None, 0, 1, 1, None) == E_SHAPE
+    # torch's calc_execution_policy on a 256-CU device: 256 * min(2048, ceil(n / 256)) threads, 4 values per thread and round
+    for n, inc in ((1, 4), (8192, 4), (8192 * 16, 4), (2048 * 256, 4), (2048 * 256 * 4, 4), (2048 * 256 * 4 + 1, 8), (32768 * 21, 4)):
+        assert lib.pqlk_philox_increment(n) == inc, n
+    assert lib.pqlk_philox_increment(0) == 0
     for code in (E_NULL, E_SHAPE, 3, E_ALIGN, E_UNSUPPORTED, 6):
         assert len(lib.pqlk_strerror(code)) > 2
 
