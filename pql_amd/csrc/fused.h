@@ -101,11 +101,11 @@ __device__ __forceinline__ void fused_group(f32x16f (&acc)[R][TPW], float4 (&bq)
 
 // ring <- the first D steps of (layer, wave)'s tiles; indices clamped so that idle waves / short layers stay in bounds
 template <int TM, int D>
-__device__ __forceinline__ void fused_ring_fill(float4 (&bq)[D][TM], const float4* __restrict__ packed_l, int K8, int ntiles, int tpw,
+__device__ __forceinline__ void fused_ring_fill(float4 (&bq)[D][TM], const float4* __restrict__ packed_l, int K8, int K8s, int ntiles, int tpw,
                                                 int wave, int lane) {
   const float4* w[TM];
 #pragma unroll
-  for (int j = 0; j < TM; ++j) w[j] = packed_l + (long long)min(wave * tpw + j, ntiles - 1) * K8 * 64 + lane;
+  for (int j = 0; j < TM; ++j) w[j] = packed_l + (long long)min(wave * tpw + j, ntiles - 1) * K8s * 64 + lane;
 #pragma unroll
   for (int s = 0; s < D; ++s) {
     const int ks = min(s, K8 - 1) * 64;
@@ -115,7 +115,7 @@ __device__ __forceinline__ void fused_ring_fill(float4 (&bq)[D][TM], const float
 }
 
 template <int R, int TPW, int TM, int D>
-__device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, int K8, int ntiles, const float4* __restrict__ packed_l,
+__device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, int K8, int K8s, int ntiles, const float4* __restrict__ packed_l,
                                             int bias_lds4, float* __restrict__ gout, int g_ld, int row0, int B, int wave, int lane,
                                             const float4* __restrict__ packed_n, int K8n, int ntiles_n, int tpw_n,
                                             float* __restrict__ gprev, int nprev4) {
@@ -144,11 +144,14 @@ __device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, in
   if (active) {
     const float4* wp[TPW];
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) wp[j] = packed_l + (long long)min(t0 + j, ntiles - 1) * K8 * 64 + lane;
+    for (int j = 0; j < TPW; ++j) wp[j] = packed_l + (long long)min(t0 + j, ntiles - 1) * K8s * 64 + lane;
     const int abase = r * buf_ld4 + h;
+    // K8 reduction steps of 8 = G whole ring groups + a remainder of 0..D-1 steps (ring slots 0.. hold those); K8s = the steps per
+    // tile in the packed copy (the padded width).  The first layer runs ceil(in / 8) steps, not ld(in) / 8: the critic's 104 inputs
+    // are 13 steps, not 16 -- the three steps of zero padding were 19 % of that layer's MFMAs (adding 0 x 0 changes no bit).
     const int K8full = K8 - (K8 % D);
     const int G = K8full / D;
-    const bool rem = D > 4 && K8full < K8;   // K8 % D == 4 (K8 is a multiple of 4): ring slots 0..3 hold those steps
+    const bool rem = K8full < K8;
     float4 an[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) an[i] = lds4[abase + 32 * i * buf_ld4];
@@ -165,14 +168,14 @@ __device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, in
       if (rem) fused_group<R, TPW, TM, D, true>(acc, bq, wp, lds4, abase, buf_ld4, (G - 1) * D, K8, D, an);
       else fused_group<R, TPW, TM, D, false>(acc, bq, wp, lds4, abase, buf_ld4, (G - 1) * D, K8, D, an);
     }
-    if (rem) fused_group<R, TPW, TM, D, false>(acc, bq, wp, lds4, abase, buf_ld4, K8full, K8, 4, an);
+    if (rem) fused_group<R, TPW, TM, D, false>(acc, bq, wp, lds4, abase, buf_ld4, K8full, K8, K8 - K8full, an);
   }
   while (srow < srows) {   // what the main loop did not cover (idle waves, short reductions)
     gprev4[(long long)srow * nprev4 + sc4] = lds4[srow * buf_ld4 + sc4];
     srow += sdq; sc4 += sdm;
     if (sc4 >= nprev4) { sc4 -= nprev4; ++srow; }
   }
-  if (packed_n) fused_ring_fill<TM, D>(bq, packed_n, K8n, ntiles_n, tpw_n, wave, lane);   // ahead of this layer's epilogue
+  if (packed_n) fused_ring_fill<TM, D>(bq, packed_n, K8n, K8n, ntiles_n, tpw_n, wave, lane);   // ahead of this layer's epilogue
   __syncthreads();   // A: every wave is done reading this layer's input
   if (active) {
     // lane (r, h) owns row r of each row tile, columns 32*tile + 8q + 4h + {0..3} (transposed-tile accumulator layout)
@@ -300,8 +303,8 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
   auto tpw_of = [](int ntiles) { return ntiles > 2 * NW ? 4 : ntiles > NW ? 2 : 1; };
   float4 bq[D][TM];
   // ring of layer 0, issued before the input tile is staged
-  fused_ring_fill<TM, D>(bq, packed_net + (p.p_off[0] >> 2), ((p.dims[0] + 31) & ~31) >> 3, p.dims[1] >> 5, tpw_of(p.dims[1] >> 5), wave,
-                         lane);
+  fused_ring_fill<TM, D>(bq, packed_net + (p.p_off[0] >> 2), (p.dims[0] + 7) >> 3, ((p.dims[0] + 31) & ~31) >> 3, p.dims[1] >> 5,
+                         tpw_of(p.dims[1] >> 5), wave, lane);
   float4* out4 = reinterpret_cast<float4*>(fsm);
   const int bias4 = 32 * R * buf_ld4;   // float4 offset of the bias table: layer l at bias4 + l * (buf_ld4 - 1)
   // Staging: every global load of the prologue (bias rows, then the input tile four quads at a time) is issued before
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
   }
   __syncthreads();
   for (int l = 0; l < p.n_hidden; ++l) {
-    const int K8 = ((p.dims[l] + 31) & ~31) >> 3, N = p.dims[l + 1], ntiles = N >> 5;
+    const int K8s = ((p.dims[l] + 31) & ~31) >> 3, K8 = (p.dims[l] + 7) >> 3, N = p.dims[l + 1], ntiles = N >> 5;
     const float4* packed_l = packed_net + (p.p_off[l] >> 2);
     const int bias_l = bias4 + l * (buf_ld4 - 1);
     const bool last = l + 1 == p.n_hidden;
@@ -366,13 +369,13 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
     const int K8n = last ? 1 : N >> 3, ntiles_n = last ? 1 : p.dims[l + 2] >> 5;
     const int tpw = tpw_of(ntiles), tpw_n = tpw_of(ntiles_n);
     if (TM >= 4 && tpw == 4)
-      fused_layer<R, (TM >= 4 ? 4 : 1), TM, D>(bq, buf_ld4, K8, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n,
+      fused_layer<R, (TM >= 4 ? 4 : 1), TM, D>(bq, buf_ld4, K8, K8s, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n,
                                                ntiles_n, tpw_n, gprev, nprev4);
     else if (tpw == 2)
-      fused_layer<R, 2, TM, D>(bq, buf_ld4, K8, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n, ntiles_n,
+      fused_layer<R, 2, TM, D>(bq, buf_ld4, K8, K8s, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n, ntiles_n,
                                tpw_n, gprev, nprev4);
     else
-      fused_layer<R, 1, TM, D>(bq, buf_ld4, K8, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n, ntiles_n,
+      fused_layer<R, 1, TM, D>(bq, buf_ld4, K8, K8s, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n, ntiles_n,
                                tpw_n, gprev, nprev4);
   }
   if (p.head_n > 0) fused_head<R>(p, pparams, pacts, net, row0, buf_ld4, wave, lane);   // the LDS buffer holds the last hidden layer's output
