@@ -566,6 +566,29 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
       const int prow = lane / LPR, pc4 = lane % LPR;
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
+        // ELU' operand of this pass: ALL of its requests go out before the patch is staged, into registers the k loop has
+        // vacated.  Written as load -> use -> store per row group (rounds 1-2 and the start of round 3) the stores to C and the
+        // next load of H may alias as far as the compiler can tell, so it put `s_waitcnt vmcnt(0)` between them: sixteen
+        // dependent load + store round trips per block, which is what made the dX products slower than the dW products of the
+        // same size (round 2 hid it behind a prefetch in front of the k loop; the stage-ahead fragments took those registers).
+        f4v h4s[(EPI == EPI_DELU) ? 32 / RPI : 1];
+        if (EPI == EPI_DELU) {
+          long long arow[32 / RPI];
+          const long long grow0 = m0 + wm + 32 * i + prow;
+          if (MODE == MODE_DX && p.perm) {   // one branch around all the index loads, so that they too are in flight together
+            int pr[32 / RPI];
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) pr[it] = p.perm[grow0 + it * RPI];
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) arow[it] = pr[it] < 0 ? 0 : pr[it];   // pad rows: dZ is zero anyway
+          } else {
+#pragma unroll
+            for (int it = 0; it < 32 / RPI; ++it) arow[it] = grow0 + it * RPI;
+          }
+#pragma unroll
+          for (int it = 0; it < 32 / RPI; ++it)
+            h4s[it] = *reinterpret_cast<const f4v*>(auxw + arow[it] * p.ldaux + n0 + wn + 4 * pc4);
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -580,12 +603,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
           const long long grow = m0 + wm + 32 * i + rr;
           const int gcol = n0 + wn + 4 * pc4;
           if (EPI == EPI_DELU) {
-            // (round 2 requested this operand before the k loop into 64 spare registers; round 3 gave those registers to the
-            //  second fragment set of the stage-ahead loop, which measured better: backward 270.3 -> 262.9 us; both together
-            //  spill the prefetch to scratch and measured worse again, 273.1 -> 276.7)
-            long long arow = grow;
-            if (MODE == MODE_DX && p.perm) { const int pr = p.perm[grow]; arow = pr < 0 ? 0 : pr; }   // pad rows: dZ is zero anyway
-            const float4 h4 = *reinterpret_cast<const float4*>(auxw + arow * p.ldaux + gcol);
+            const f4v h4 = h4s[it];
             v.x = h4.x > 0.f ? v.x : v.x * (h4.x + 1.f);  // ELU'(x) = exp(x) = elu(x) + 1 for x <= 0
             v.y = h4.y > 0.f ? v.y : v.y * (h4.y + 1.f);
             v.z = h4.z > 0.f ? v.z : v.z * (h4.z + 1.f);
