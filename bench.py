@@ -67,6 +67,9 @@ def parse():
     ap.add_argument("--no-streams", action="store_true", help="serialise V / P / rollout on one stream")
     ap.add_argument("--no-fused", action="store_true", help="per-layer GEMM launches instead of the fused hidden-layer forward")
     ap.add_argument("--no-fused-tail", action="store_true", help="separate loss-fold / gradient-norm launches (A/B of algo.fused_tail)")
+    ap.add_argument("--dp-buckets", default="auto", choices=["auto", "layer", "one"],
+                    help="data parallel: the critic's gradient all-reduce in per-layer buckets issued behind each layer's slab sum, "
+                         "as one collective after the whole backward, or auto = layer iff PQL_DP_GRAPH_COLLECTIVE=1 (algo.dp_buckets)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the roofline / free-running sections after the timed blocks (rocprofv3 kernel-trace runs: the CSV's "
@@ -115,6 +118,7 @@ def build_system(args, rank, world, device, pg, learner_device=None):
     cfg = load_cfg(ov)
     cfg.algo.hidden_layers = hidden
     cfg.algo.fused_tail = not getattr(args, "no_fused_tail", False)
+    cfg.algo.dp_buckets = getattr(args, "dp_buckets", "auto")
     cfg.algo.rng = getattr(args, "rng", "auto")
     cfg.algo.reward_scale = 0.01   # preprocess_cfg's AllegroHand value (common.py:159-170)
     sh = getattr(args, "shard", None)
@@ -632,7 +636,8 @@ def main():
                    "parallelism": par, "layout": args.layout if args.gpus > 1 else "single", "ranks": world,
                    "per_rank": {"num_envs": args.num_envs, "replay_rows": args.replay, "batch": args.batch},
                    "job": {"num_envs": args.shard.total_envs, "replay_rows": args.replay * world, "batch": args.batch * world},
-                   "backend": backend, "share_gpu": bool(args.share_gpu)},
+                   "backend": backend, "share_gpu": bool(args.share_gpu),
+                   "grad_buckets": (len(v._buckets) if getattr(v, "_buckets", None) else 1) if getattr(v, "dp", False) else None},
         "repeats": {"blocks": len(blocks), "steps_per_block": args.steps, "median": rates[len(rates) // 2], "min": rates[0],
                     "max": rates[-1], "note": "`value` is the first block; same unit"},
         "p_grad_steps_per_s": value / int(cfg.algo.critic_actor_ratio) if mode == "schedule" else 0.0,

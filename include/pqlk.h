@@ -231,6 +231,19 @@ int pqlk_mlp_backward_td(const PqlMlpDesc* d, const float* params, const float* 
                          float* sumsq_part, int32_t* step_dev, pqlk_stream_t stream);
 int32_t pqlk_td_head_loss_parts(const PqlMlpDesc* d, int64_t b);   /* 0: this layout cannot take pqlk_mlp_backward_td */
 
+/* Data-parallel buckets (the gradient all-reduce "overlapped with the last dW GEMMs"; the reference has no
+ * counterpart, its learners are single-GPU -- pql_v_learner.py:110-113 is `backward(); step()`).  Layers layer_hi >= l >=
+ * layer_lo of the backward above (dW_l, db_l, dX_l) and then the split-slab reduction of exactly those layers into `grads`:
+ * what this call leaves in grads is final, so its all-reduce can be issued while the calls for the layers below still run.
+ * Calls walk the layers downwards (first: layer_hi = n_layers - 1, last: layer_lo = 0) over the SAME workspace; their union
+ * leaves in grads bit for bit what one pqlk_mlp_backward / pqlk_mlp_backward_td call leaves.  dy is read by the call holding
+ * the last layer; give acts_target / rew / done / loss_part (all four or none) and that call forms the TD error in the head
+ * pass as pqlk_mlp_backward_td does (dy is then ignored). */
+int pqlk_mlp_backward_layers(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                             const float* acts, const float* dy, const float* acts_target, const float* rew,
+                             const float* done, float gamma_n, float* loss_part, float* grads, int32_t splits,
+                             float* ws, int64_t ws_floats, int32_t layer_hi, int32_t layer_lo, pqlk_stream_t stream);
+
 /* The learners' random draws with torch's own numbers (csrc/philox.hip; reference draws: pql/replay/simple_replay.py:87,
  * pql/utils/noise.py:20-21, pql/algo/pql_p_learner.py:49).  `chunks` consecutive learner steps in ONE launch: per step n_idx
  * int64 indices uniform on [0, range) into idx[chunk][n_idx], then n_normal standard normals into normal[chunk][n_normal]

@@ -28,6 +28,7 @@ from pql_amd import _lib as L
 from pql_amd.models import model_name_to_path
 from pql_amd.models.mlp import PackedWeights, default_splits, mlp_forward_raw, output_view
 from pql_amd.replay.simple_replay import ReplayBuffer
+from pql_amd.utils import dp as DP
 from pql_amd.utils import handoff as H
 from pql_amd.utils import rng as R
 from pql_amd.utils.common import Tracker, load_class_from_path
@@ -258,6 +259,21 @@ class PQLVLearner:
         self.normalize_tuple = None
         self.sleep_time = 0
         self.use_graph = bool(_cfg_get(algo, "graph", False))
+        # data parallel, algo.dp_buckets: "layer" = the gradient travels in per-layer buckets, each all-reduced as soon as its dW
+        # slabs are summed, under the MFMA launches of the layers below (pql_amd/utils/dp.py); "one" = a single collective after
+        # the whole backward; "auto" (default) = layer when the collectives are captured inside the step's hipGraph
+        # (PQL_DP_GRAPH_COLLECTIVE=1), else one: with eager collectives every bucket ends a graph, and on the one rank this pool
+        # can run those extra graph boundaries cost more (1114 vs 1164 steps/s) than a 1-rank collective can give back
+        self._buckets = None
+        if self.dp and self.critic.layout.n_layers >= 3:
+            mode = str(_cfg_get(algo, "dp_buckets", "auto"))
+            if mode not in ("auto", "layer", "one"):
+                raise ValueError(f"algo.dp_buckets must be auto, layer or one, got {mode!r}")
+            if mode == "auto":
+                mode = "layer" if self.use_graph and graph_collective_enabled(self.pg) else "one"
+            if mode == "layer":
+                self._buckets = DP.layer_buckets(self.critic.layout.n_layers)
+                self._reducer = DP.BucketAllReduce(self.pg)
         # RNG draws inside the hipGraph or in front of it.  In front (default): torch hands a captured generator its seed and
         # Philox offset through two 1-element fill launches per replay (~9 us of device time per step, more than the draws save
         # by being captured), and the graph no longer bakes in the randint bound, so it is not re-captured while the ring fills.
@@ -366,6 +382,8 @@ class PQLVLearner:
         # scalar twin heads: TD target + MSE + dL/dQ are formed inside the head's backward pass (one launch less)
         ws["td_parts"] = int(L.lib.pqlk_td_head_loss_parts(C.byref(cl.desc), B)) if (self._fold_loss and self._td_in_head
                                                                                       and not self.cfg.algo.distl) else 0
+        if self._buckets is not None:
+            ws["bucket_views"] = [DP.bucket_views(ws["grads"], cl, hi, lo) for hi, lo in self._buckets]
         self._ws = ws
         self.repack()
         return ws
@@ -414,56 +432,75 @@ class PQLVLearner:
         self._ahead.refill(self.memory.cur_capacity)
         self._gather(ws, self._ahead.idx, K * B, ws["x_sa_all"], ws["xn_sa_all"], ws["rew_all"], ws["done_all"])
 
-    def _step_kernels(self, ws, idx, draw, upto_backward=False, tiles=None):
+    def _step_kernels(self, ws, idx, draw, upto_backward=False, tiles=None, part=None):
         """The launch sequence of one critic gradient step; everything asynchronous on the current stream.
         upto_backward=True stops after the gradient is formed (graph capture around the DP all-reduce).
-        tiles: input tiles already gathered by `_prefetch` (a slot of ws["slots"]); None = gather `idx` into slot 0 here."""
+        tiles: input tiles already gathered by `_prefetch` (a slot of ws["slots"]); None = gather `idx` into slot 0 here.
+        part (data-parallel buckets, graph capture): only the forward passes + bucket 0 (part = 0) or bucket `part` of the
+        backward, no collective."""
         algo, dev, B = self.cfg.algo, self.device, ws["B"]
         O = self.memory.ring.O
         st = L.stream(dev)
         actor_in_sa = self.pk_actor is not None and self.pk_actor.tensor is not None
         if tiles is None:
             tiles = ws["slots"][0]
-            self._gather(ws, idx, B, tiles["x_sa"], tiles["xn_sa"], tiles["rew"], tiles["done"])
+            if part in (None, 0):
+                self._gather(ws, idx, B, tiles["x_sa"], tiles["xn_sa"], tiles["rew"], tiles["done"])
         ws = dict(ws, **tiles)   # the step below reads its inputs from `tiles`
         al, cl = self.actor.layout, self.critic.layout
-        # target policy smoothing (:63-71): a' written into the action columns of the target critic's input.
-        # The two no-grad chains (actor, target critic) skip the activation stash; the critic keeps it for backward.
-        xn_act = ws["xn_sa"][:, O:]
-        mlp_forward_raw(al, self.actor.arena.data, ws["xn_sa"] if actor_in_sa else ws["xn_obs"], L.ACT_TANH_NOISE, draw, algo.noise.tgt_pol_std,
-                        algo.noise.tgt_pol_noise_bound, ws["acts_a"], xn_act, packed=self.pk_actor, stash_all=False)
-        mlp_forward_raw(cl, self.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"], packed=self.pk_target,
-                        stash_all=False)
-        mlp_forward_raw(cl, self.critic.arena.data, ws["x_sa"], L.ACT_NONE, acts=ws["acts_c"], packed=self.pk_critic,
-                        stash_all=True)
-        q = output_view(cl, ws["acts_c"], B)
-        qt = output_view(cl, ws["acts_t"], B)
         gamma_n = float(algo.gamma) ** int(algo.nstep)
         # single GPU: the loss fold and the gradient-norm pass ride in launches that exist anyway (backward's slab
         # reduction, the optimiser); data parallel keeps them apart because the all-reduce sits in between
         tail = self._fused_tail
-        loss_out = None if self._fold_loss else L.ptr(self.loss_ring)
+        if part in (None, 0):
+            # target policy smoothing (:63-71): a' written into the action columns of the target critic's input.
+            # The two no-grad chains (actor, target critic) skip the activation stash; the critic keeps it for backward.
+            xn_act = ws["xn_sa"][:, O:]
+            mlp_forward_raw(al, self.actor.arena.data, ws["xn_sa"] if actor_in_sa else ws["xn_obs"], L.ACT_TANH_NOISE, draw, algo.noise.tgt_pol_std,
+                            algo.noise.tgt_pol_noise_bound, ws["acts_a"], xn_act, packed=self.pk_actor, stash_all=False)
+            mlp_forward_raw(cl, self.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"], packed=self.pk_target,
+                            stash_all=False)
+            mlp_forward_raw(cl, self.critic.arena.data, ws["x_sa"], L.ACT_NONE, acts=ws["acts_c"], packed=self.pk_critic,
+                            stash_all=True)
+            if ws["td_parts"] == 0:
+                q = output_view(cl, ws["acts_c"], B)
+                qt = output_view(cl, ws["acts_t"], B)
+                loss_out = None if self._fold_loss else L.ptr(self.loss_ring)
+                if algo.distl:
+                    L.check(L.lib.pqlk_c51_bce_loss(L.ptr(q), L.ptr(qt), cl.ld_out, int(algo.num_atoms), L.ptr(ws["rew"]),
+                                                    L.ptr(ws["done"]), L.ptr(self.critic.z_atoms), gamma_n, float(algo.v_min),
+                                                    float(algo.v_max), B, L.ptr(ws["dy"]), loss_out, L.ptr(self.opt.step),
+                                                    LOSS_RING, None, L.ptr(ws["scratch"]), st))
+                else:
+                    L.check(L.lib.pqlk_td_mse_loss(L.ptr(q), L.ptr(qt), cl.ld_out, L.ptr(ws["rew"]), L.ptr(ws["done"]), gamma_n, B,
+                                                   L.ptr(ws["dy"]), loss_out, L.ptr(self.opt.step), LOSS_RING,
+                                                   L.ptr(ws["scratch"]), st))
+        if self._buckets is not None:
+            # data parallel: the chain in pieces, each ending with the sum of its layers' dW slabs; that piece's collective goes
+            # out right behind it and runs under the launches of the layers below
+            td = ws["td_parts"] > 0
+            for k, (hi, lo) in enumerate(self._buckets):
+                if part is not None and part != k:
+                    continue
+                L.check(L.lib.pqlk_mlp_backward_layers(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
+                                                       L.ptr(ws["acts_c"]), None if td else L.ptr(ws["dy"]),
+                                                       L.ptr(ws["acts_t"]) if td else None, L.ptr(ws["rew"]) if td else None,
+                                                       L.ptr(ws["done"]) if td else None, gamma_n, L.ptr(ws["scratch"]) if td else None,
+                                                       L.ptr(ws["grads"]), ws["splits"], L.ptr(ws["bwd"]), ws["bwd"].numel(), hi, lo, st))
+                if part is None:
+                    self._reducer.issue(ws["bucket_views"][k])
+            if part is not None:
+                return
+            self._reducer.wait()
+            self._step_post(ws)
+            return
         if ws["td_parts"] > 0:
             L.check(L.lib.pqlk_mlp_backward_td(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
                                                L.ptr(ws["acts_c"]), L.ptr(ws["acts_t"]), L.ptr(ws["rew"]), L.ptr(ws["done"]), gamma_n,
                                                L.ptr(ws["scratch"]), L.ptr(ws["grads"]), ws["splits"], L.ptr(ws["bwd"]),
                                                ws["bwd"].numel(), L.ptr(self.opt.scratch) if tail else None,
                                                L.ptr(self.opt.step) if tail else None, st))
-            if upto_backward:
-                return
-            self._allreduce_grads(ws)
-            self._step_post(ws)
-            return
-        if algo.distl:
-            L.check(L.lib.pqlk_c51_bce_loss(L.ptr(q), L.ptr(qt), cl.ld_out, int(algo.num_atoms), L.ptr(ws["rew"]),
-                                            L.ptr(ws["done"]), L.ptr(self.critic.z_atoms), gamma_n, float(algo.v_min),
-                                            float(algo.v_max), B, L.ptr(ws["dy"]), loss_out, L.ptr(self.opt.step),
-                                            LOSS_RING, None, L.ptr(ws["scratch"]), st))
-        else:
-            L.check(L.lib.pqlk_td_mse_loss(L.ptr(q), L.ptr(qt), cl.ld_out, L.ptr(ws["rew"]), L.ptr(ws["done"]), gamma_n, B,
-                                           L.ptr(ws["dy"]), loss_out, L.ptr(self.opt.step), LOSS_RING,
-                                           L.ptr(ws["scratch"]), st))
-        if tail:
+        elif tail:
             L.check(L.lib.pqlk_mlp_backward_norm(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
                                                  L.ptr(ws["acts_c"]), L.ptr(ws["dy"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0,
                                                  0, None, 0, L.ptr(ws["bwd"]), ws["bwd"].numel(), L.ptr(self.opt.scratch),
@@ -501,10 +538,10 @@ class PQLVLearner:
         torch.randint(self.memory.cur_capacity, (ws["B"],), generator=self.gen, out=ws["idx"])   # straight into the workspace: no copy launch
         ws["draw"].normal_(generator=self.gen)
 
-    def _draw_and_step(self, ws, upto_backward=False, draw=True):
+    def _draw_and_step(self, ws, upto_backward=False, draw=True, part=None):
         if draw:
             self._draws(ws)
-        self._step_kernels(ws, ws["idx"], ws["draw"], upto_backward)
+        self._step_kernels(ws, ws["idx"], ws["draw"], upto_backward, part=part)
 
     @torch.no_grad()
     def learn(self, indices=None, noise=None):
@@ -541,10 +578,7 @@ class PQLVLearner:
                     if slot not in self._slot_graphs:
                         with H.CAPTURE_LOCK:
                             self._capture(ws, key, slot)
-                    self._slot_graphs[slot].replay()
-                    if self._graph_post is not None:   # data parallel: the collective stays outside the graphs
-                        self._allreduce_grads(ws)
-                        self._graph_post.replay()
+                    self._replay(ws, self._slot_graphs[slot])
                 else:
                     self._step_kernels(ws, None, self._ahead.normal[slot], tiles=ws["slots"][slot])
             elif self.use_graph:
@@ -554,14 +588,26 @@ class PQLVLearner:
                         self._capture(ws, key)
                 if not self._graph_rng:
                     self._draws(ws)
-                self._graph.replay()
-                if self._graph_post is not None:   # data parallel: the collective stays outside the graphs
-                    self._allreduce_grads(ws)
-                    self._graph_post.replay()
+                self._replay(ws, self._graph)
             else:
                 self._draw_and_step(ws)
             self.update_count += 1   # under the lock: update() reads it together with the device loss ring (free-running threads)
         return self.sleep_time
+
+    def _replay(self, ws, g):
+        """g: the step's hipGraph, or (data parallel, collectives kept eager) the list of its pieces: one graph up to the
+        gradient + ONE all-reduce, or one graph per bucket with that bucket's all-reduce issued behind it; then the optimiser's."""
+        if isinstance(g, list):
+            for k, piece in enumerate(g):
+                piece.replay()
+                self._reducer.issue(ws["bucket_views"][k])
+            self._reducer.wait()
+            self._graph_post.replay()
+            return
+        g.replay()
+        if self._graph_post is not None:   # data parallel: the collective stays outside the graphs
+            self._allreduce_grads(ws)
+            self._graph_post.replay()
 
     @torch.no_grad()
     def prepare(self):
@@ -602,8 +648,8 @@ class PQLVLearner:
         if slot is None:
             step = lambda **kw: self._draw_and_step(ws, **kw)   # noqa: E731
         else:
-            def step(upto_backward=False, draw=None):
-                self._step_kernels(ws, None, self._ahead.normal[slot], upto_backward, tiles=ws["slots"][slot])
+            def step(upto_backward=False, draw=None, part=None):
+                self._step_kernels(ws, None, self._ahead.normal[slot], upto_backward, tiles=ws["slots"][slot], part=part)
         # warm-up outside capture (lazy hipFuncSetAttribute / allocator state), on a side stream as torch requires
         snap = self._snapshot()
         s = torch.cuda.Stream(self.device)
@@ -619,8 +665,14 @@ class PQLVLearner:
             with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
                 step(draw=self._graph_rng)
         else:   # two graphs around the RCCL all-reduce (kept eager: no collective is ever captured)
-            with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
-                step(upto_backward=True, draw=self._graph_rng)
+            if self._buckets is not None:   # ... or one per gradient bucket, each followed by its own collective
+                g = [g] + [self._new_graph() for _ in self._buckets[1:]]
+                for k, piece in enumerate(g):
+                    with torch.cuda.graph(piece, stream=self._capture_stream, capture_error_mode="thread_local"):
+                        step(part=k, draw=self._graph_rng and k == 0)
+            else:
+                with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
+                    step(upto_backward=True, draw=self._graph_rng)
             if slot is None or self._graph_post is None:   # (the optimiser graph is the same for every slot)
                 g_post = self._new_graph()
                 with torch.cuda.graph(g_post, stream=self._capture_stream, capture_error_mode="thread_local"):

@@ -1123,6 +1123,7 @@ struct ReduceP {
   const float* slabs; int splits; long long n;
   float* out;
   const float* head_part; int head_parts; int n_nets; long long net_stride, head_off, head_floats;
+  long long seg_off, seg_len;   // the arena range [seg_off, seg_off + seg_len) of every net is reduced (whole arena: 0, net_stride)
   int main_blocks;
   float* sq_part; int32_t* step_dev;
 };
@@ -1131,18 +1132,18 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(ReduceP p) {
   __shared__ float shw[4];
   float acc = 0.f;
   if ((int)blockIdx.x < p.main_blocks) {
-    const long long n4 = p.n >> 2;  // arena sizes are multiples of 32 floats
+    const long long sq = p.seg_len >> 2, n4 = sq * p.n_nets;  // layer blocks start and end on multiples of 32 floats
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)p.main_blocks * 256) {
-      if (p.head_parts > 0) {   // block boundaries are multiples of 32 floats: a quad never straddles
-        const long long off = i << 2;
-        if (off - (off / p.net_stride) * p.net_stride >= p.head_off) continue;
-      }
-      float4 s = reinterpret_cast<const float4*>(p.slabs)[i];
+      long long q = i, base = p.seg_off;
+      while (q >= sq) { q -= sq; base += p.net_stride; }
+      if (p.head_parts > 0 && p.seg_off + (q << 2) >= p.head_off) continue;   // a quad never straddles the head's start
+      const long long off = base + (q << 2);
+      float4 s = *reinterpret_cast<const float4*>(p.slabs + off);
       for (int k = 1; k < p.splits; ++k) {
-        const float4 t = reinterpret_cast<const float4*>(p.slabs + (long long)k * p.n)[i];
+        const float4 t = *reinterpret_cast<const float4*>(p.slabs + (long long)k * p.n + off);
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
       }
-      reinterpret_cast<float4*>(p.out)[i] = s;
+      *reinterpret_cast<float4*>(p.out + off) = s;
       acc += (s.x * s.x + s.y * s.y) + (s.z * s.z + s.w * s.w);
     }
     if (!p.sq_part) return;
@@ -1203,10 +1204,16 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
                              const float* acts, const float* dy, float* grads, int32_t splits, float* dx,
                              int64_t ld_dx, int32_t dx_col0, int32_t dx_cols, const float* dx_tanh_of,
                              int64_t ld_tanh, float* ws, int64_t ws_floats, float* sq_part, int32_t* step_dev,
-                             pqlk_stream_t stream, const TdHead* td = nullptr) {
+                             pqlk_stream_t stream, const TdHead* td = nullptr, int l_hi = -1, int l_lo = 0) {
+  // l_hi >= 0: only layers l_hi >= l >= l_lo of the chain (dW_l, dX_l) and the slab reduction of exactly those layers (the
+  // data-parallel buckets of pqlk_mlp_backward_layers); calls must walk the layers downwards over the same workspace
   int rc = desc_ok(d);
   if (rc) return rc;
-  PQLK_REQUIRE(params && x && acts && (dy || td) && ws, PQLK_E_NULL);
+  const bool ranged = l_hi >= 0;
+  if (!ranged) l_hi = d->n_layers - 1;
+  PQLK_REQUIRE(l_lo >= 0 && l_lo <= l_hi && l_hi < d->n_layers, PQLK_E_RANGE);
+  PQLK_REQUIRE(!ranged || (grads && !dx && !sq_part), PQLK_E_UNSUPPORTED);
+  PQLK_REQUIRE(params && x && acts && (dy || td || l_hi < d->n_layers - 1) && ws, PQLK_E_NULL);
   if (td) PQLK_REQUIRE(grads && d->n_nets == 2 && d->dims[d->n_layers] == 1 && head_is_fused(d), PQLK_E_UNSUPPORTED);
   PQLK_REQUIRE(b > 0 && b < (1LL << 30), PQLK_E_SHAPE);
   PQLK_REQUIRE(ldx % 32 == 0 && ldx >= pqlk_ld(d->dims[0]), PQLK_E_ALIGN);
@@ -1232,9 +1239,10 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
   int head_blocks = 0;   // > 0: the last layer's dW / db are per-block partials in head_part
   hipStream_t st = pqlk_s(stream);
 
-  const float* cur_dy = dy;  // (n_nets, b, ld(out_l))
-  int flip = 0;
-  for (int l = L - 1; l >= 0; --l) {
+  for (int l = l_hi; l >= l_lo; --l) {
+    // layer l reads dL/dZ_l from where layer l + 1 left it and writes dL/dZ_{l-1} into the other buffer
+    const float* cur_dy = l == L - 1 ? dy : dact[(L - 2 - l) & 1];  // (n_nets, b, ld(out_l))
+    const int flip = (L - 1 - l) & 1;
     int64_t w_off, b_off;
     pqlk_mlp_layer_offsets(d, l, &w_off, &b_off);
     const int64_t ld_out = pqlk_ld(d->dims[l + 1]);
@@ -1268,8 +1276,6 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
         }
         rc = launch_skinny_bwd(q, d->n_nets, head_part, (long long)(net_stride - w_off), st);
         if (rc) return rc;
-        cur_dy = dact[flip];
-        flip ^= 1;
         continue;
       }
       if (grads) {
@@ -1284,8 +1290,6 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
         q.epi = SK_EPI_DELU;
         rc = launch_skinny_dx(q, d->n_nets, st);
         if (rc) return rc;
-        cur_dy = dact[flip];
-        flip ^= 1;
         continue;
       }
       if (!dx) continue;
@@ -1318,8 +1322,6 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
       p.epi = EPI_DELU;
       rc = launch_auto<MODE_DX>(p, d->n_nets, st);
       if (rc) return rc;
-      cur_dy = dact[flip];
-      flip ^= 1;
     } else if (dx) {  // input gradient, summed over nets
       GemmP p = {};
       p.A = cur_dy; p.lda = (int)ld_out; p.sA = b * ld_out;
@@ -1342,11 +1344,15 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
     ReduceP r = {};
     r.slabs = slabs; r.splits = splits; r.n = arena; r.out = grads;
     r.head_part = head_part; r.head_parts = head_blocks; r.n_nets = d->n_nets; r.net_stride = net_stride;
-    int64_t w_last, b_last;
+    int64_t w_last, b_last, w_lo, w_next, b_tmp;
     pqlk_mlp_layer_offsets(d, L - 1, &w_last, &b_last);
     r.head_off = w_last; r.head_floats = net_stride - w_last;
+    pqlk_mlp_layer_offsets(d, l_lo, &w_lo, &b_tmp);
+    w_next = net_stride;
+    if (l_hi < L - 1) pqlk_mlp_layer_offsets(d, l_hi + 1, &w_next, &b_tmp);
+    r.seg_off = w_lo; r.seg_len = w_next - w_lo;   // layers sit in ascending order inside a net's block
     r.sq_part = sq_part; r.step_dev = step_dev;
-    r.main_blocks = reduce_main_blocks(arena, sq_part != nullptr);   // with sq_part: at most 1024 + head blocks partials
+    r.main_blocks = reduce_main_blocks(r.seg_len * d->n_nets, sq_part != nullptr);   // with sq_part: at most 1024 + head blocks partials
     const int extra = head_blocks > 0 ? (int)((head_quads(d) + 3) / 4) : 0;
     hipLaunchKernelGGL(k_reduce_slabs, dim3(r.main_blocks + extra), dim3(256), 0, st, r);
     PQLK_LAUNCH_CHECK();
@@ -1488,6 +1494,37 @@ extern "C" int pqlk_mlp_backward_td(const PqlMlpDesc* d, const float* params, co
   const TdHead td = {acts_target + q_off, rew, done, gamma_n, loss_part};
   return mlp_backward_impl(d, params, x, ldx, b, acts, nullptr, grads, splits, nullptr, 0, 0, 0, nullptr, 0, ws, ws_floats, sumsq_part,
                            step_dev, stream, &td);
+}
+
+// Data-parallel buckets: layers layer_hi >= l >= layer_lo of the same backward (dW_l, dX_l) followed by the slab reduction of
+// exactly those layers into `grads`, so that their all-reduce can be issued while the launches of the layers below still run.
+// Calls walk the layers downwards (layer_hi of the first = n_layers - 1, layer_lo of the last = 0) over the SAME workspace;
+// the union of the calls leaves in `grads` the bits one pqlk_mlp_backward / pqlk_mlp_backward_td call leaves (every arena
+// element is the same fixed-order sum).  dy is read by the call that holds the last layer only; with acts_target / rew / done /
+// loss_part given (all four, else all NULL and dy non-NULL) that call forms the TD error in the head pass like
+// pqlk_mlp_backward_td.
+extern "C" int pqlk_mlp_backward_layers(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                                        const float* acts, const float* dy, const float* acts_target, const float* rew,
+                                        const float* done, float gamma_n, float* loss_part, float* grads, int32_t splits, float* ws,
+                                        int64_t ws_floats, int32_t layer_hi, int32_t layer_lo, pqlk_stream_t stream) {
+  int rc = desc_ok(d);
+  if (rc) return rc;
+  PQLK_REQUIRE(grads, PQLK_E_NULL);
+  PQLK_REQUIRE(layer_lo >= 0 && layer_lo <= layer_hi && layer_hi < d->n_layers, PQLK_E_RANGE);
+  const bool any_td = acts_target || rew || done || loss_part, all_td = acts_target && rew && done && loss_part;
+  PQLK_REQUIRE(any_td == all_td, PQLK_E_NULL);
+  if (all_td && layer_hi == d->n_layers - 1) {
+    PQLK_REQUIRE(b > 0, PQLK_E_SHAPE);
+    int64_t q_off, q_ld;
+    rc = pqlk_mlp_act_offset(d, b, 0, d->n_layers - 1, &q_off, &q_ld);
+    if (rc) return rc;
+    const TdHead td = {acts_target + q_off, rew, done, gamma_n, loss_part};
+    return mlp_backward_impl(d, params, x, ldx, b, acts, nullptr, grads, splits, nullptr, 0, 0, 0, nullptr, 0, ws, ws_floats, nullptr,
+                             nullptr, stream, &td, layer_hi, layer_lo);
+  }
+  PQLK_REQUIRE(all_td || dy || layer_hi < d->n_layers - 1, PQLK_E_NULL);
+  return mlp_backward_impl(d, params, x, ldx, b, acts, dy, grads, splits, nullptr, 0, 0, 0, nullptr, 0, ws, ws_floats, nullptr, nullptr,
+                           stream, nullptr, layer_hi, layer_lo);
 }
 
 extern "C" int32_t pqlk_td_head_loss_parts(const PqlMlpDesc* d, int64_t b) {

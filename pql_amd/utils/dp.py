@@ -65,3 +65,60 @@ def component_groups(pg, names=("v", "p", "rms")):
     backend = dist.get_backend(pg)
     ranks = dist.get_process_group_ranks(pg)
     return {n: dist.new_group(ranks=ranks, backend=backend) for n in names}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Gradient buckets (SURVEY 8e: the all-reduce "overlapped with the last dW GEMMs").  The backward walks the layers from the
+# head down; a layer's gradient is final as soon as its dW product's split slabs are summed, long before the first layer's
+# launches.  `pqlk_mlp_backward_layers` runs the chain in pieces that end with that sum, and each piece's all-reduce is
+# issued asynchronously on the component's communicator right behind it: the collective of the upper layers travels over
+# xGMI while the MFMA launches of the layers below run.  Every arena element is the same fixed-order sum and the same
+# rank-order reduction as in the one-bucket path, only in another launch: the gradient bits do not change.
+def layer_buckets(n_layers):
+    """[(layer_hi, layer_lo), ...] from the head down.  The head (a few hundred floats) shares the first bucket with the last
+    hidden layer: a collective of its own would be all latency."""
+    n_layers = int(n_layers)
+    if n_layers < 3:
+        return [(n_layers - 1, 0)]
+    return [(n_layers - 1, n_layers - 2)] + [(l, l) for l in range(n_layers - 3, -1, -1)]
+
+
+def bucket_views(grads, layout, layer_hi, layer_lo):
+    """The arena ranges of layers layer_lo..layer_hi: one contiguous 1-D view of `grads` per net (layers sit in ascending
+    order inside a net's block, nets one after the other)."""
+    lo = layout.w_off[layer_lo]
+    hi = layout.net_stride if layer_hi == layout.n_layers - 1 else layout.w_off[layer_hi + 1]
+    return [grads[n * layout.net_stride + lo: n * layout.net_stride + hi] for n in range(layout.n_nets)]
+
+
+class BucketAllReduce:
+    """Issues the buckets' sum-all-reduces without waiting for them; `wait()` orders the current stream behind all of them
+    (and is where the optimiser may start).  RCCL: one grouped launch per bucket (`allreduce_coalesced`: the per-net ranges of
+    a bucket are not adjacent in the arena) on the communicator's own stream, which waits for the issuing stream's position at
+    the call.  gloo (CPU tests, one-card rehearsals): staged through host memory, synchronous -- same sums."""
+
+    def __init__(self, pg):
+        import torch.distributed as dist
+        self.pg = pg
+        self.backend = dist.get_backend(pg)
+        self.pending = []
+
+    def issue(self, views):
+        import torch
+        import torch.distributed as dist
+        if self.backend == "gloo" and views[0].is_cuda:
+            for v in views:
+                h = v.cpu()
+                dist.all_reduce(h, group=self.pg)
+                v.copy_(h)
+            return
+        opts = dist.AllreduceCoalescedOptions()
+        opts.reduceOp = dist.ReduceOp.SUM
+        if hasattr(opts, "asyncOp"):
+            opts.asyncOp = True
+        self.pending.append(self.pg.allreduce_coalesced(list(views), opts))
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []

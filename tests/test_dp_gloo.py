@@ -223,3 +223,36 @@ def test_strong_scaling_two_ranks_reproduce_the_one_process_gradient():
     full = torch.cat([g.reshape(-1) for g in grads]).numpy()
     np.testing.assert_allclose(g0, full, rtol=1e-5, atol=1e-9)
     assert abs(0.5 * (l0 + l1) - float(loss.detach())) <= 1e-6 * max(1.0, abs(float(loss.detach())))   # mean of rank means == global batch mean
+
+
+# --------------------------------------------------------------------------- gradient buckets (all-reduce behind backward)
+def _buckets(rank, world):
+    """The per-layer buckets tile a twin critic's gradient arena exactly once, and their grouped all-reduces leave what one
+    all-reduce of the whole arena leaves (CPU tensors through the same BucketAllReduce the learner uses)."""
+    from pql_amd.models.mlp import ArenaLayout
+    from pql_amd.utils.dp import BucketAllReduce, bucket_views, layer_buckets
+    lay = ArenaLayout([104, 512, 512, 256, 1], 2)     # configs[1]: obs 88 + act 16
+    bk = layer_buckets(lay.n_layers)
+    assert bk == [(3, 2), (1, 1), (0, 0)] and layer_buckets(2) == [(1, 0)] and layer_buckets(5) == [(4, 3), (2, 2), (1, 1), (0, 0)]
+    g = T(dd.uniform((lay.total,), 40 + rank, -1, 1)).clone()
+    cover = torch.zeros(lay.total, dtype=torch.int32)
+    for hi, lo in bk:
+        for v, c in zip(bucket_views(g, lay, hi, lo), bucket_views(cover, lay, hi, lo)):
+            assert v.is_contiguous() and v.storage_offset() % 32 == 0 and v.numel() % 32 == 0   # 128-B aligned ranges of the arena
+            c += 1
+    assert bool((cover == 1).all())                   # every arena element in exactly one bucket
+    for net in range(lay.n_nets):                     # ... and the head's block sits in the first one, with the last hidden layer
+        v = bucket_views(g, lay, *bk[0])[net]
+        assert v.numel() == lay.net_stride - lay.w_off[2]
+    whole = g.clone()
+    dist.all_reduce(whole)
+    red = BucketAllReduce(dist.group.WORLD)
+    for hi, lo in bk:
+        red.issue(bucket_views(g, lay, hi, lo))
+    red.wait()
+    return np.array_equal(g.numpy(), whole.numpy()), float(whole.abs().sum())
+
+
+def test_gradient_buckets_tile_the_arena_and_sum_like_one_all_reduce():
+    a, b = run2(_buckets)
+    assert a[0] and b[0] and a[1] == b[1] and a[1] > 0

@@ -295,6 +295,13 @@ def test_c_abi_reports_argument_errors_as_codes():
     assert lib.pqlk_mlp_backward_td(C.byref(d1), P, P, 32, 4, P, P, P, P, 0.97, P, P, 1, P, 1 << 20, None, None, None) == E_UNSUPPORTED  # one net
     assert lib.pqlk_td_head_loss_parts(C.byref(d), 8192) == 512 and lib.pqlk_td_head_loss_parts(C.byref(d1), 8192) == 0
     assert lib.pqlk_td_head_loss_parts(C.byref(L.mlp_desc([8, 64, 51], 2)), 8192) == 0                                    # C51 heads: own loss kernel
+    # data-parallel buckets: layer ranges are checked before anything is launched
+    bl = lib.pqlk_mlp_backward_layers
+    assert bl(C.byref(d), P, P, 32, 4, P, P, None, None, None, 0.97, None, P, 1, P, 1 << 20, 2, 0, None) == E_RANGE      # 2 layers: 0..1
+    assert bl(C.byref(d), P, P, 32, 4, P, P, None, None, None, 0.97, None, P, 1, P, 1 << 20, 0, 1, None) == E_RANGE      # hi < lo
+    assert bl(C.byref(d), P, P, 32, 4, P, P, None, None, None, 0.97, None, None, 1, P, 1 << 20, 1, 0, None) == E_NULL    # no gradient arena
+    assert bl(C.byref(d), P, P, 32, 4, P, P, P, None, None, 0.97, None, P, 1, P, 1 << 20, 1, 0, None) == E_NULL          # TD inputs: all four or none
+    assert bl(C.byref(d), P, P, 32, 4, P, None, None, None, None, 0.97, None, P, 1, P, 1 << 20, 1, 1, None) == E_NULL    # the head's call needs dy
     assert lib.pqlk_philox_draws(1, 0, 0, None, 100, None, 8, None, 0, 1, 1, None) == E_NULL
     assert lib.pqlk_philox_draws(1, 0, 0, None, 1 << 28, P, 8, None, 0, 1, 1, None) == E_RANGE       # torch draws 64-bit values from 2^28 on
     assert lib.pqlk_philox_draws(1, 2, 0, None, 100, P, 8, None, 0, 1, 1, None) == E_ALIGN          # offsets advance in whole Philox blocks

@@ -738,6 +738,17 @@ def test_mlp_shape_sweep_vs_oracle(dev, ref, dims, nets, B, fused):
             scale = np.abs(gw).max() + 1e-12
             np.testing.assert_allclose(lay.weight(grads, n, l).cpu().numpy(), gw, rtol=1e-4, atol=2e-5 * scale, err_msg=f"dW net {n} layer {l}")
             np.testing.assert_allclose(lay.bias(grads, n, l).cpu().numpy(), gb, rtol=1e-4, atol=2e-5 * max(scale, np.abs(gb).max()), err_msg=f"db net {n} layer {l}")
+    # data-parallel buckets (pqlk_mlp_backward_layers): the same chain run in layer ranges, each ending with the slab sum of its
+    # own layers, leaves the same gradient bits -- the learner's bucket list and one bucket per layer
+    from pql_amd.utils.dp import layer_buckets
+    for buckets in (layer_buckets(lay.n_layers), [(l, l) for l in range(lay.n_layers - 1, -1, -1)]):
+        g2 = torch.zeros_like(arena)
+        for hi, lo in buckets:
+            L.check(L.lib.pqlk_mlp_backward_layers(C.byref(lay.desc), L.ptr(arena), L.ptr(x), lay.ld_in, B, L.ptr(acts), L.ptr(dy), None, None,
+                                                   None, 0.0, None, L.ptr(g2), splits, L.ptr(ws), ws.numel(), hi, lo, L.stream(dev)))
+        for n in range(nets):
+            for l in range(lay.n_layers):
+                assert torch.equal(lay.weight(g2, n, l), lay.weight(grads, n, l)) and torch.equal(lay.bias(g2, n, l), lay.bias(grads, n, l)), (buckets, n, l)
 
 
 # --------------------------------------------------------------------------- one-launch rollout bookkeeping

@@ -513,6 +513,68 @@ def test_data_parallel_two_ranks_match_single_gpu_step(golden, dev):
     assert np.array_equal(ret[0]["graph"], ret[1]["graph"])
 
 
+def _dp_bucket_rank(rank, port, ret):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)   # RCCL with one rank: the production collectives, nothing to sum
+    try:
+        from pql_amd.algo.pql_v_learner import PQLVLearner
+        from pql_amd.models.mlp import TanhMLPPolicy
+        from pql_amd.utils.dp import component_groups
+        dev = torch.device("cuda:0")
+        O, A, B = 24, 6, 1024
+        pg = component_groups(dist.group.WORLD, ("v",))["v"]
+        outs = {}
+        for distl in (False, True):
+            for name, buckets, graph, captured in (("one_eager", "one", False, "0"), ("layer_eager", "layer", False, "0"),
+                                                   ("one_graph", "one", True, "0"), ("layer_graph", "layer", True, "0"),
+                                                   ("layer_graph_captured_collectives", "layer", True, "1")):
+                os.environ["PQL_DP_GRAPH_COLLECTIVE"] = captured
+                cfg = make_cfg(distl, B=B, memory=5000, hidden=[256, 256, 128], graph=graph)
+                cfg.algo.dp_buckets = buckets
+                v = PQLVLearner((O,), A, cfg, process_group=pg)
+                assert (v._buckets == [(3, 2), (1, 1), (0, 0)]) if buckets == "layer" else v._buckets is None
+                K = 51 if distl else 1
+                v.critic.load_state_dict(_sd(dd.doubleq_state(O, A, K, 21, hidden=[256, 256, 128])))
+                v.critic_target.arena.data.copy_(v.critic.arena.data)
+                actor = TanhMLPPolicy((O,), A, hidden_layers=[256, 256, 128]).to(dev)
+                actor.load_state_dict(_sd(dd.mlp_state(O, A, 11, hidden=[256, 256, 128])))
+                v.update(actor, tuple(t.to(dev) for t in _fill(O, A, 3000, 810)), None, 0)
+                v.use_private_rng(99)
+                for _ in range(4):
+                    v.learn()
+                torch.cuda.synchronize()
+                outs[(distl, name)] = (v.critic.arena.data.cpu().numpy(), v._ws["grads"].cpu().numpy(), v.loss_ring.cpu().numpy(),
+                                       int(v.opt.step.item()))
+        ret[0] = outs
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_buckets_leave_the_bits_of_the_single_collective(dev):
+    """SURVEY 8(e), the all-reduce overlapped with backward: the critic's gradient all-reduced in per-layer buckets issued
+    behind each layer's slab sum (`algo.dp_buckets=layer`: pqlk_mlp_backward_layers + one grouped RCCL launch per bucket) must
+    leave the gradient, the parameters and the losses of the one-collective path bit for bit -- eager, as one hipGraph per
+    bucket around eager collectives, and with the collectives captured; scalar and C51 heads.  One RCCL rank (the only
+    RCCL this pool can run); the two-rank sum is covered with gloo by test_data_parallel_two_ranks_match_single_gpu_step."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    mgr = mp.Manager(); ret = mgr.dict()
+    mp.spawn(_dp_bucket_rank, args=(port, ret), nprocs=1, join=True)
+    outs = ret[0]
+    for distl in (False, True):
+        ref = outs[(distl, "one_eager")]
+        assert ref[3] == 4 and np.isfinite(ref[0]).all() and np.abs(ref[1]).max() > 0
+        for name in ("layer_eager", "one_graph", "layer_graph", "layer_graph_captured_collectives"):
+            got = outs[(distl, name)]
+            for a, b, what in zip(ref, got, ("parameters", "gradient", "loss ring", "step count")):
+                assert np.array_equal(a, b), f"{name} (distl={distl}): {what} differ from the single-collective eager path"
+
+
 # --------------------------------------------------------------------------- evaluator (SURVEY 8f rank 2)
 @pytest.mark.parametrize("subprocess_mode", [False, True])
 def test_evaluator_on_gpu_matches_plain_rollout(dev, tmp_path, subprocess_mode):
