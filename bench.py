@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--dp-buckets", default="auto", choices=["auto", "layer", "one"],
                     help="data parallel: the critic's gradient all-reduce in per-layer buckets issued behind each layer's slab sum, "
                          "as one collective after the whole backward, or auto = layer iff PQL_DP_GRAPH_COLLECTIVE=1 (algo.dp_buckets)")
+    ap.add_argument("--no-td-forward", action="store_true", help="head backward as its own launch instead of inside the critic's forward (A/B of algo.td_in_forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the roofline / free-running sections after the timed blocks (rocprofv3 kernel-trace runs: the CSV's "
@@ -119,6 +120,7 @@ def build_system(args, rank, world, device, pg, learner_device=None):
     cfg.algo.hidden_layers = hidden
     cfg.algo.fused_tail = not getattr(args, "no_fused_tail", False)
     cfg.algo.dp_buckets = getattr(args, "dp_buckets", "auto")
+    cfg.algo.td_in_forward = not getattr(args, "no_td_forward", False)
     cfg.algo.rng = getattr(args, "rng", "auto")
     cfg.algo.reward_scale = 0.01   # preprocess_cfg's AllegroHand value (common.py:159-170)
     sh = getattr(args, "shard", None)

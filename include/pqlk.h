@@ -231,6 +231,22 @@ int pqlk_mlp_backward_td(const PqlMlpDesc* d, const float* params, const float* 
                          float* sumsq_part, int32_t* step_dev, pqlk_stream_t stream);
 int32_t pqlk_td_head_loss_parts(const PqlMlpDesc* d, int64_t b);   /* 0: this layout cannot take pqlk_mlp_backward_td */
 
+/* The same scalar-head step with the head's backward inside the critic's FORWARD launch: pqlk_mlp_forward_td is
+ * pqlk_mlp_forward(packed, stash_all = 1, PQLK_ACT_NONE) whose blocks, having formed Q for their rows, also form the TD error
+ * (pql_v_learner.py:104-108), dL/dZ of the last hidden layer, the head's dW / db partials and the loss partials while that
+ * layer's activations are still in LDS -- no head-backward launch, no second read of them (and no stash of them: that block of
+ * `acts` is left unwritten).  bwd_ws / splits: the workspace and split count the backward will be called with.  Follow with
+ * pqlk_mlp_backward_td_tail (same arguments as pqlk_mlp_backward_td minus the TD inputs): layers n_layers-2 .. 0 and the slab
+ * reduction.  loss_part receives pqlk_td_forward_loss_parts(d, b) partials (0: this layout / batch cannot take the path: no
+ * fused hidden stack, not a twin scalar head, or no room beside the last hidden layer in LDS). */
+int32_t pqlk_td_forward_loss_parts(const PqlMlpDesc* d, int64_t b);
+int pqlk_mlp_forward_td(const PqlMlpDesc* d, const float* params, const float* packed, const float* x, int64_t ldx, int64_t b,
+                        float* acts, const float* acts_target, const float* rew, const float* done, float gamma_n,
+                        float* loss_part, float* bwd_ws, int64_t bwd_ws_floats, int32_t splits, pqlk_stream_t stream);
+int pqlk_mlp_backward_td_tail(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                              const float* acts, float* grads, int32_t splits, float* ws, int64_t ws_floats,
+                              float* sumsq_part, int32_t* step_dev, pqlk_stream_t stream);
+
 /* Data-parallel buckets (the gradient all-reduce "overlapped with the last dW GEMMs"; the reference has no
  * counterpart, its learners are single-GPU -- pql_v_learner.py:110-113 is `backward(); step()`).  Layers layer_hi >= l >=
  * layer_lo of the backward above (dW_l, db_l, dX_l) and then the split-slab reduction of exactly those layers into `grads`:

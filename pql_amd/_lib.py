@@ -58,6 +58,9 @@ PROTOTYPES = {
     "pqlk_mlp_norm_parts": (_I32, [C.POINTER(PqlMlpDesc)]),
     "pqlk_mlp_backward_td": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _P, _P, _F, _P, _P, _I32, _P, _I64, _P, _P, _P]),
     "pqlk_td_head_loss_parts": (_I32, [C.POINTER(PqlMlpDesc), _I64]),
+    "pqlk_td_forward_loss_parts": (_I32, [C.POINTER(PqlMlpDesc), _I64]),
+    "pqlk_mlp_forward_td": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _F, _P, _P, _I64, _I32, _P]),
+    "pqlk_mlp_backward_td_tail": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P, _P, _P]),
     "pqlk_mlp_backward_layers": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _F, _P, _P, _I32, _P, _I64, _I32, _I32, _P]),
     "pqlk_dpg_backward_ws_floats": (_I64, [C.POINTER(PqlMlpDesc), _I64]),
     "pqlk_dpg_critic_backward": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _I32, _P, _I64, _P, _P, _I64, _P]),

@@ -382,6 +382,14 @@ class PQLVLearner:
         # scalar twin heads: TD target + MSE + dL/dQ are formed inside the head's backward pass (one launch less)
         ws["td_parts"] = int(L.lib.pqlk_td_head_loss_parts(C.byref(cl.desc), B)) if (self._fold_loss and self._td_in_head
                                                                                       and not self.cfg.algo.distl) else 0
+        # ... and with the fused forward the head's whole backward runs inside the critic's forward launch, off the activations still
+        # in LDS: the head-backward launch and its second read of them disappear (algo.td_in_forward; not with gradient buckets)
+        ws["td_fwd"] = 0
+        if ws["td_parts"] > 0 and bool(_cfg_get(self.cfg.algo, "td_in_forward", True)) and self._buckets is None \
+                and self.pk_critic is not None and self.pk_critic.tensor is not None:
+            ws["td_fwd"] = int(L.lib.pqlk_td_forward_loss_parts(C.byref(cl.desc), B))
+            if ws["td_fwd"] > 0:
+                ws["td_parts"] = ws["td_fwd"]
         if self._buckets is not None:
             ws["bucket_views"] = [DP.bucket_views(ws["grads"], cl, hi, lo) for hi, lo in self._buckets]
         self._ws = ws
@@ -460,8 +468,13 @@ class PQLVLearner:
                             algo.noise.tgt_pol_noise_bound, ws["acts_a"], xn_act, packed=self.pk_actor, stash_all=False)
             mlp_forward_raw(cl, self.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"], packed=self.pk_target,
                             stash_all=False)
-            mlp_forward_raw(cl, self.critic.arena.data, ws["x_sa"], L.ACT_NONE, acts=ws["acts_c"], packed=self.pk_critic,
-                            stash_all=True)
+            if ws["td_fwd"] > 0:
+                L.check(L.lib.pqlk_mlp_forward_td(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(self.pk_critic.tensor), L.ptr(ws["x_sa"]),
+                                                  ws["ld_sa"], B, L.ptr(ws["acts_c"]), L.ptr(ws["acts_t"]), L.ptr(ws["rew"]), L.ptr(ws["done"]),
+                                                  gamma_n, L.ptr(ws["scratch"]), L.ptr(ws["bwd"]), ws["bwd"].numel(), ws["splits"], st))
+            else:
+                mlp_forward_raw(cl, self.critic.arena.data, ws["x_sa"], L.ACT_NONE, acts=ws["acts_c"], packed=self.pk_critic,
+                                stash_all=True)
             if ws["td_parts"] == 0:
                 q = output_view(cl, ws["acts_c"], B)
                 qt = output_view(cl, ws["acts_t"], B)
@@ -494,7 +507,11 @@ class PQLVLearner:
             self._reducer.wait()
             self._step_post(ws)
             return
-        if ws["td_parts"] > 0:
+        if ws["td_fwd"] > 0:
+            L.check(L.lib.pqlk_mlp_backward_td_tail(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
+                                                    L.ptr(ws["acts_c"]), L.ptr(ws["grads"]), ws["splits"], L.ptr(ws["bwd"]), ws["bwd"].numel(),
+                                                    L.ptr(self.opt.scratch) if tail else None, L.ptr(self.opt.step) if tail else None, st))
+        elif ws["td_parts"] > 0:
             L.check(L.lib.pqlk_mlp_backward_td(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
                                                L.ptr(ws["acts_c"]), L.ptr(ws["acts_t"]), L.ptr(ws["rew"]), L.ptr(ws["done"]), gamma_n,
                                                L.ptr(ws["scratch"]), L.ptr(ws["grads"]), ws["splits"], L.ptr(ws["bwd"]),

@@ -44,6 +44,17 @@ struct FusedP {
   const float* draw;                           // (B, head_n) standard-normal draw for HEAD_TANH_NOISE
   float* out2;                                 // optional second destination of the output (net 0), row stride ld_out2
   float noise_std, noise_clip;
+  // optional TD head (td_dz != NULL; scalar twin-Q head, head_n == 1, two nets): the block forms the TD error of its rows from the
+  // Q it has just computed and leaves the head's whole backward -- dL/dZ of the last hidden layer, the head's dW / db partial and
+  // the loss partial -- while that layer's activations are still in LDS (fused_head_td below)
+  const float* td_qt;        // target critic's head output, (2, B, head_ld)
+  const float* td_rew;       // (B)
+  const float* td_done;      // (B)
+  float td_gamma_n, td_two_over_b;
+  float* td_dz;              // (n_nets, B, dims[n_hidden]) dL/dZ of the last hidden layer
+  float* td_head_part;       // [row tile][net][td_part_floats]: W row (dims[n_hidden] floats), then ld(1) = 32 bias floats
+  long long td_part_floats;
+  float* td_loss_part;       // [row tile][net] sum of (Q - y)^2 over the tile's rows
 };
 
 
@@ -214,7 +225,7 @@ __device__ __forceinline__ void fused_layer(float4 (&bq)[D][TM], int buf_ld4, in
 // each); the summation order differs from theirs by reassociation only.
 enum { HEAD_NONE = PQLK_ACT_NONE, HEAD_TANH = PQLK_ACT_TANH, HEAD_TANH_NOISE = PQLK_ACT_TANH_NOISE };
 
-template <int R>
+template <int R, bool TDH = true>
 __device__ __forceinline__ void fused_head(const FusedP& p, const float* __restrict__ params, float* __restrict__ acts, int net, int row0,
                                            int buf_ld4, int wave, int lane) {
   constexpr int NW = FUSED_NW;
@@ -240,24 +251,41 @@ __device__ __forceinline__ void fused_head(const FusedP& p, const float* __restr
       acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4.w, a4.w, acc[i], 0, 0, 0);
     }
   }
+  // The partial tiles (NW x R x 16 x 64 floats) go over the activation buffer once every wave has read it -- except with the TD
+  // head, which still needs the activations: there they go into the 256 columns to the right of them (float x of the partial
+  // area sits in row x / 256; the host checked buf_ld - Kh >= 256, and 32 R rows x 256 = the NW x R x 1024 floats needed).
+  const bool td = TDH && p.td_dz != nullptr;
+  auto part_at = [&](int x) { return td ? (x >> 8) * p.buf_ld + Kh + (x & 255) : x; };
   __syncthreads();   // every wave is done reading the activations
 #pragma unroll
   for (int i = 0; i < R; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) fsm[((wave * R + i) * 16 + e) * 64 + lane] = acc[i][e];
+    for (int e = 0; e < 16; ++e) fsm[part_at(((wave * R + i) * 16 + e) * 64 + lane)] = acc[i][e];
   __syncthreads();
   const float* bias = params + (long long)net * p.net_stride + p.head_b_off;
   float* out = acts + p.head_a_off + (long long)net * p.B * p.head_ld;
+  const int tdbase = 32 * R * p.buf_ld;   // TD: [0, 32 R) 2/B (Q - y) per row, [32 R, 64 R) (Q - y)^2; over the bias table (no longer read)
   for (int o = wave * 64 + lane; o < 32 * R * p.head_ld; o += 64 * NW) {
     const int row = o / p.head_ld, c = o - row * p.head_ld;
-    if (row0 + row >= p.B) continue;
+    if (row0 + row >= p.B) {
+      if (td && c == 0) { fsm[tdbase + row] = 0.f; fsm[tdbase + 32 * R + row] = 0.f; }
+      continue;
+    }
     float x = 0.f;   // pad column
     if (c < N) {
       const int i = row >> 5, ln = (row & 31) + 32 * ((c >> 2) & 1), e = 4 * (c >> 3) + (c & 3);   // accumulator slot of (row, c)
       float s = 0.f;
 #pragma unroll
-      for (int w = 0; w < NW; ++w) s += fsm[((w * R + i) * 16 + e) * 64 + ln];
+      for (int w = 0; w < NW; ++w) s += fsm[part_at(((w * R + i) * 16 + e) * 64 + ln)];
       x = s + bias[c];
+      if (td) {   // N == 1: this thread holds Q(row) of this block's net.  y = r + (1-d) gamma^n min Q'  (pql_v_learner.py:104-108)
+        const long long m = row0 + row;
+        const float t1 = p.td_qt[m * p.head_ld], t2 = p.td_qt[((long long)p.B + m) * p.head_ld];
+        const float y = p.td_rew[m] + ((1.f - p.td_done[m]) * p.td_gamma_n) * fminf(t1, t2);
+        const float dq = x - y;
+        fsm[tdbase + row] = p.td_two_over_b * dq;
+        fsm[tdbase + 32 * R + row] = dq * dq;
+      }
       if (p.head_epi == HEAD_TANH) x = tanhf(x);
       else if (p.head_epi == HEAD_TANH_NOISE) {
         x = tanhf(x);
@@ -268,6 +296,62 @@ __device__ __forceinline__ void fused_head(const FusedP& p, const float* __restr
       if (p.out2 && net == 0) p.out2[(long long)(row0 + row) * p.ld_out2 + c] = x;
     }
     out[(long long)(row0 + row) * p.head_ld + c] = x;
+  }
+  if (!td) return;
+  // ---- the head's backward for this block's rows, off the activations still in LDS (what k_skinny_bwd<1, CH, true> does in a
+  // launch of its own after re-reading them from HBM): dZ = dQ w * ELU'(h), bit for bit its values; dW / db / loss partials in a
+  // fixed order (rows ascending inside a wave, then the waves 0..7), folded later by k_reduce_slabs / k_adamw like k_skinny_bwd's.
+  __syncthreads();   // dQ of every row is in LDS; nobody reads the partial tiles any more
+  const int kq = Kh >> 2;
+  const int tile = row0 / (32 * R);
+  float* dz = p.td_dz + ((long long)net * p.B + row0) * Kh;
+  for (int e0 = wave * 64 + lane; e0 < 32 * R * kq; e0 += 64 * NW) {
+    const int row = e0 / kq, q = e0 - row * kq;
+    const float4 h4 = lds4[row * buf_ld4 + q];
+    const float4 w4 = *reinterpret_cast<const float4*>(W + 4 * q);
+    const float dn = fsm[tdbase + row];
+    float4 a = make_float4(dn * w4.x, dn * w4.y, dn * w4.z, dn * w4.w);
+    a.x = h4.x > 0.f ? a.x : a.x * (h4.x + 1.f);   // ELU'(x) = elu(x) + 1 for x <= 0
+    a.y = h4.y > 0.f ? a.y : a.y * (h4.y + 1.f);
+    a.z = h4.z > 0.f ? a.z : a.z * (h4.z + 1.f);
+    a.w = h4.w > 0.f ? a.w : a.w * (h4.w + 1.f);
+    if (row0 + row < p.B) *reinterpret_cast<float4*>(dz + (long long)row * Kh + 4 * q) = a;
+  }
+  // dW partial: wave w sums its 4 R rows for every column quad (lane = quad, chunks of 64 quads), parks the sum in the free
+  // columns of row w, and the block's first waves add the eight in wave order
+  constexpr int RW = 32 * R / NW;
+  float* hp = p.td_head_part + ((long long)tile * p.n_nets + net) * p.td_part_floats;
+  for (int q0 = 0; q0 < kq; q0 += 64) {
+    const int q = q0 + lane;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (q < kq) {
+#pragma unroll
+      for (int u = 0; u < RW; ++u) {
+        const int row = wave * RW + u;
+        const float dn = fsm[tdbase + row];
+        const float4 h4 = lds4[row * buf_ld4 + q];
+        s.x += dn * h4.x; s.y += dn * h4.y; s.z += dn * h4.z; s.w += dn * h4.w;
+      }
+    }
+    __syncthreads();   // (the previous chunk's sums have been folded)
+    if (q < kq) *reinterpret_cast<float4*>(&fsm[wave * p.buf_ld + Kh + 4 * lane]) = s;
+    __syncthreads();
+    if (wave == 0 && q < kq) {
+      float4 t = *reinterpret_cast<const float4*>(&fsm[Kh + 4 * lane]);
+#pragma unroll
+      for (int w = 1; w < NW; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(&fsm[w * p.buf_ld + Kh + 4 * lane]);
+        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+      }
+      *reinterpret_cast<float4*>(hp + 4 * q) = t;
+    }
+  }
+  if (wave == 1 && lane < 32) {   // db (+ the zero pad of the bias block) and the loss partial: rows in ascending order
+    float db = 0.f, ls = 0.f;
+    if (lane == 0)
+      for (int row = 0; row < 32 * R; ++row) { db += fsm[tdbase + row]; ls += fsm[tdbase + 32 * R + row]; }
+    hp[Kh + lane] = lane == 0 ? db : 0.f;
+    if (lane == 0) p.td_loss_part[(long long)tile * p.n_nets + net] = ls;
   }
 }
 
@@ -361,7 +445,7 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
     // layer's main loop (deferred: full tiles of a stashing forward)
     const bool defer = pstash && full_tile;
     // (a forward-only call whose output layer is fused needs no HBM copy of the last hidden layer at all)
-    const bool keep_last = last && (pstash || p.head_n == 0);
+    const bool keep_last = last && (pstash || p.head_n == 0) && !p.td_dz;   // (the TD head consumes the last hidden layer in LDS: backward never reads it)
     float* gout = (keep_last || (pstash && !full_tile)) ? pacts + p.a_off[l] + (long long)net * p.B * N : nullptr;
     float* gprev = (defer && l > 0) ? pacts + p.a_off[l - 1] + (long long)net * p.B * p.dims[l] : nullptr;
     const int nprev4 = p.dims[l] >> 2;

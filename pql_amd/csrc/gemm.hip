@@ -899,7 +899,8 @@ static int64_t max_hidden_ld(const PqlMlpDesc* d) {
 static int64_t head_part_floats(const PqlMlpDesc* d, int64_t b) {   // room for k_skinny_bwd's per-block partials
   const int L = d->n_layers;
   const int64_t hf = (int64_t)d->dims[L] * pqlk_ld(d->dims[L - 1]) + pqlk_ld(d->dims[L]);
-  return (int64_t)skinny_bwd_blocks(b, d->n_nets) * d->n_nets * hf;
+  const int64_t skinny = skinny_bwd_blocks(b, d->n_nets), tiles = (b + 31) / 32;   // k_skinny_bwd's blocks; the fused forward's TD head
+  return (skinny > tiles ? skinny : tiles) * d->n_nets * hf;                         // leaves one per row tile of 32 or 64
 }
 
 extern "C" int64_t pqlk_mlp_bwd_ws_floats(const PqlMlpDesc* d, int64_t b, int32_t splits) {
@@ -973,11 +974,32 @@ struct FusedHead {   // output layer to run inside the fused launch (n = 0: none
   float noise_std, noise_clip;
   float* out2;
   int64_t ld_out2;
+  // TD head (pqlk_mlp_forward_td): see FusedP
+  const float* td_qt; const float* td_rew; const float* td_done; float td_gamma_n;
+  float* td_dz; float* td_head_part; float* td_loss_part;
 };
 
 // the output layer can ride along when it is at most one 32-column tile wide and the last hidden width is a multiple of 32
 static bool head_fusable(const PqlMlpDesc* d) {
   return d->n_layers >= 2 && d->dims[d->n_layers] <= 32 && d->dims[d->n_layers - 1] % 32 == 0;
+}
+
+// rows per block of the fused forward, in tiles of 32: 2 (64 rows) when no hidden layer is wider than 512 (two output tiles per
+// wave, 132 KB of LDS) and the halved grid still fills the 256 CUs about as well -- cost model: rounds x rows per block, 32-row
+// blocks ~15 % less efficient per row.  PQLK_FUSED_ROWS = 32 / 64 overrides (tuning).
+static int fused_rows(const PqlMlpDesc* d, int buf_ld, int64_t b) {
+  bool wide = false;
+  for (int l = 1; l < d->n_layers; ++l) wide = wide || d->dims[l] > 512;
+  int R = 1;
+  if (!wide && fused_lds_bytes(d, buf_ld, 2) <= 160 * 1024) {
+    const int64_t b1 = ((b + 31) / 32) * d->n_nets, b2 = ((b + 63) / 64) * d->n_nets;
+    const double c1 = 1.15 * (double)((b1 + 255) / 256), c2 = 2.0 * (double)((b2 + 255) / 256);
+    if (c2 <= c1) R = 2;
+    static const int forced = [] { const char* e = getenv("PQLK_FUSED_ROWS"); return e ? atoi(e) : 0; }();
+    if (forced == 32) R = 1;
+    if (forced == 64) R = 2;
+  }
+  return R;
 }
 
 static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const float* packed, const float* x, int64_t ldx,
@@ -1005,21 +1027,16 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
     p.head_n = head->n; p.head_epi = head->epi; p.head_ld = (int)a_ld; p.ld_out2 = (int)head->ld_out2;
     p.head_w_off = w_off; p.head_b_off = b_off; p.head_a_off = a_off;
     p.draw = head->draw; p.out2 = head->out2; p.noise_std = head->noise_std; p.noise_clip = head->noise_clip;
+    if (head->td_dz) {
+      p.td_qt = head->td_qt; p.td_rew = head->td_rew; p.td_done = head->td_done; p.td_gamma_n = head->td_gamma_n;
+      p.td_two_over_b = 2.0f / (float)b;
+      p.td_dz = head->td_dz; p.td_head_part = head->td_head_part; p.td_loss_part = head->td_loss_part;
+      p.td_part_floats = p.net_stride - w_off;
+    }
   }
-  // rows per block: 64 (R = 2) when no hidden layer is wider than 512 (two output tiles per wave, 132 KB of LDS) and the
-  // halved grid still fills the 256 CUs about as well -- cost model: rounds x rows per block, 32-row blocks ~15 % less
-  // efficient per row.  PQLK_FUSED_ROWS = 32 / 64 overrides (tuning).
   bool wide = false;
   for (int l = 1; l < d->n_layers; ++l) wide = wide || d->dims[l] > 512;
-  int R = 1;
-  if (!wide && fused_lds_bytes(d, buf_ld, 2) <= 160 * 1024) {
-    const int64_t b1 = ((b + 31) / 32) * d->n_nets, b2 = ((b + 63) / 64) * d->n_nets;
-    const double c1 = 1.15 * (double)((b1 + 255) / 256), c2 = 2.0 * (double)((b2 + 255) / 256);
-    if (c2 <= c1) R = 2;
-    static const int forced = [] { const char* e = getenv("PQLK_FUSED_ROWS"); return e ? atoi(e) : 0; }();
-    if (forced == 32) R = 1;
-    if (forced == 64) R = 2;
-  }
+  const int R = fused_rows(d, buf_ld, b);
   static PqlkPerDeviceOnce attr_once;
   if (attr_once.need()) {
     const void* ks[3] = {reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 2>), reinterpret_cast<const void*>(&k_mlp_fwd_fused<2, 2>),
@@ -1204,7 +1221,9 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
                              const float* acts, const float* dy, float* grads, int32_t splits, float* dx,
                              int64_t ld_dx, int32_t dx_col0, int32_t dx_cols, const float* dx_tanh_of,
                              int64_t ld_tanh, float* ws, int64_t ws_floats, float* sq_part, int32_t* step_dev,
-                             pqlk_stream_t stream, const TdHead* td = nullptr, int l_hi = -1, int l_lo = 0) {
+                             pqlk_stream_t stream, const TdHead* td = nullptr, int l_hi = -1, int l_lo = 0, int head_done = 0) {
+  // head_done > 0: the last layer's backward already ran inside the fused forward (pqlk_mlp_forward_td): dL/dZ of the last hidden
+  // layer sits in the first dZ buffer and `head_done` row-tile partials of the head's dW / db in the partial area
   // l_hi >= 0: only layers l_hi >= l >= l_lo of the chain (dW_l, dX_l) and the slab reduction of exactly those layers (the
   // data-parallel buckets of pqlk_mlp_backward_layers); calls must walk the layers downwards over the same workspace
   int rc = desc_ok(d);
@@ -1213,7 +1232,8 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
   if (!ranged) l_hi = d->n_layers - 1;
   PQLK_REQUIRE(l_lo >= 0 && l_lo <= l_hi && l_hi < d->n_layers, PQLK_E_RANGE);
   PQLK_REQUIRE(!ranged || (grads && !dx && !sq_part), PQLK_E_UNSUPPORTED);
-  PQLK_REQUIRE(params && x && acts && (dy || td || l_hi < d->n_layers - 1) && ws, PQLK_E_NULL);
+  PQLK_REQUIRE(params && x && acts && (dy || td || head_done || l_hi < d->n_layers - 1) && ws, PQLK_E_NULL);
+  PQLK_REQUIRE(!head_done || (!ranged && grads && !dx && !td && d->n_layers >= 2), PQLK_E_UNSUPPORTED);
   if (td) PQLK_REQUIRE(grads && d->n_nets == 2 && d->dims[d->n_layers] == 1 && head_is_fused(d), PQLK_E_UNSUPPORTED);
   PQLK_REQUIRE(b > 0 && b < (1LL << 30), PQLK_E_SHAPE);
   PQLK_REQUIRE(ldx % 32 == 0 && ldx >= pqlk_ld(d->dims[0]), PQLK_E_ALIGN);
@@ -1236,10 +1256,10 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
   float* dact[2] = {ws, ws + dbuf};
   float* slabs = ws + 2 * dbuf;
   float* head_part = slabs + (int64_t)splits * arena;
-  int head_blocks = 0;   // > 0: the last layer's dW / db are per-block partials in head_part
+  int head_blocks = head_done;   // > 0: the last layer's dW / db are per-block partials in head_part
   hipStream_t st = pqlk_s(stream);
 
-  for (int l = l_hi; l >= l_lo; --l) {
+  for (int l = head_done ? l_hi - 1 : l_hi; l >= l_lo; --l) {
     // layer l reads dL/dZ_l from where layer l + 1 left it and writes dL/dZ_{l-1} into the other buffer
     const float* cur_dy = l == L - 1 ? dy : dact[(L - 2 - l) & 1];  // (n_nets, b, ld(out_l))
     const int flip = (L - 1 - l) & 1;
@@ -1525,6 +1545,66 @@ extern "C" int pqlk_mlp_backward_layers(const PqlMlpDesc* d, const float* params
   PQLK_REQUIRE(all_td || dy || layer_hi < d->n_layers - 1, PQLK_E_NULL);
   return mlp_backward_impl(d, params, x, ldx, b, acts, dy, grads, splits, nullptr, 0, 0, 0, nullptr, 0, ws, ws_floats, nullptr, nullptr,
                            stream, nullptr, layer_hi, layer_lo);
+}
+
+// ---- the same step with the head's backward inside the critic's fused FORWARD launch (fused.h, fused_head's TD part): the
+// k_skinny_bwd launch and its second read of the last hidden layer's activations disappear.
+// Row tiles of the fused forward when this layout can take it, else 0: twin net, one output, fused hidden stack + fused head, the
+// head's partials in k_skinny_bwd's format, 256 free LDS columns beside the last hidden layer for the head's partial tiles.
+static int64_t td_forward_tiles(const PqlMlpDesc* d, int64_t b) {
+  int buf_ld = 0;
+  const int L = d->n_layers;
+  if (b <= 0 || !fusable(d, &buf_ld) || !head_fusable(d) || getenv("PQLK_NO_FUSED_HEAD")) return 0;
+  if (d->n_nets != 2 || d->dims[L] != 1 || !head_is_fused(d)) return 0;
+  if (buf_ld - d->dims[L - 1] < 256 || (int64_t)(L - 1) * (buf_ld - 4) < 128) return 0;
+  const int R = fused_rows(d, buf_ld, b);
+  return (b + 32 * R - 1) / (32 * R);
+}
+
+extern "C" int32_t pqlk_td_forward_loss_parts(const PqlMlpDesc* d, int64_t b) {
+  if (desc_ok(d)) return 0;
+  return (int32_t)(td_forward_tiles(d, b) * d->n_nets);
+}
+
+extern "C" int pqlk_mlp_forward_td(const PqlMlpDesc* d, const float* params, const float* packed, const float* x, int64_t ldx,
+                                   int64_t b, float* acts, const float* acts_target, const float* rew, const float* done,
+                                   float gamma_n, float* loss_part, float* bwd_ws, int64_t bwd_ws_floats, int32_t splits,
+                                   pqlk_stream_t stream) {
+  int rc = desc_ok(d);
+  if (rc) return rc;
+  PQLK_REQUIRE(params && packed && x && acts && acts_target && rew && done && loss_part && bwd_ws, PQLK_E_NULL);
+  PQLK_REQUIRE(b > 0 && b < (1LL << 30), PQLK_E_SHAPE);
+  PQLK_REQUIRE(ldx % 32 == 0 && ldx >= pqlk_ld(d->dims[0]), PQLK_E_ALIGN);
+  PQLK_REQUIRE(pqlk_aligned16(params) && pqlk_aligned16(packed) && pqlk_aligned16(x) && pqlk_aligned16(acts) && pqlk_aligned16(bwd_ws),
+               PQLK_E_ALIGN);
+  PQLK_REQUIRE(td_forward_tiles(d, b) > 0, PQLK_E_UNSUPPORTED);
+  PQLK_REQUIRE(splits >= 1 && splits <= 64, PQLK_E_SHAPE);
+  PQLK_REQUIRE(bwd_ws_floats >= pqlk_mlp_bwd_ws_floats(d, b, splits), PQLK_E_WORKSPACE);
+  const int L = d->n_layers;
+  int64_t q_off, q_ld;
+  rc = pqlk_mlp_act_offset(d, b, 0, L - 1, &q_off, &q_ld);
+  if (rc) return rc;
+  FusedHead head = {};
+  head.n = 1; head.epi = PQLK_ACT_NONE;
+  head.td_qt = acts_target + q_off; head.td_rew = rew; head.td_done = done; head.td_gamma_n = gamma_n;
+  // the workspace layout of mlp_backward_impl: two dZ buffers, the split slabs, the head's partials
+  head.td_dz = bwd_ws;
+  head.td_head_part = bwd_ws + 2 * (int64_t)d->n_nets * b * max_hidden_ld(d) + (int64_t)splits * pqlk_mlp_param_floats(d);
+  head.td_loss_part = loss_part;
+  return launch_fused_hidden(d, params, packed, x, ldx, b, acts, 1, pqlk_s(stream), &head);
+}
+
+extern "C" int pqlk_mlp_backward_td_tail(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,
+                                         const float* acts, float* grads, int32_t splits, float* ws, int64_t ws_floats,
+                                         float* sumsq_part, int32_t* step_dev, pqlk_stream_t stream) {
+  int rc = desc_ok(d);
+  if (rc) return rc;
+  PQLK_REQUIRE(grads, PQLK_E_NULL);
+  PQLK_REQUIRE((sumsq_part == nullptr) == (step_dev == nullptr), PQLK_E_NULL);
+  const int64_t tiles = td_forward_tiles(d, b);
+  PQLK_REQUIRE(tiles > 0, PQLK_E_UNSUPPORTED);
+  return mlp_backward_impl(d, params, x, ldx, b, acts, nullptr, grads, splits, nullptr, 0, 0, 0, nullptr, 0, ws, ws_floats, sumsq_part,
+                           step_dev, stream, nullptr, -1, 0, (int)tiles);
 }
 
 extern "C" int32_t pqlk_td_head_loss_parts(const PqlMlpDesc* d, int64_t b) {

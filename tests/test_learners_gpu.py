@@ -310,6 +310,7 @@ def test_td_in_head_matches_the_separate_loss_launch(dev):
     for td in (True, False):
         cfg = make_cfg(False, B=B, memory=cap, hidden=[512, 512, 256])
         cfg.algo.td_in_head = td
+        cfg.algo.td_in_forward = False   # (the head's backward inside the FORWARD launch sums the head's partials in other groups: next test)
         v = PQLVLearner((O,), A, cfg)
         v.critic.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 61, (512, 512, 256))))
         v.critic_target.arena.data.copy_(v.critic.arena.data)
@@ -326,6 +327,51 @@ def test_td_in_head_matches_the_separate_loss_launch(dev):
         assert torch.equal(a, b)
     torch.testing.assert_close(outs[0][-1], outs[1][-1], rtol=1e-6, atol=1e-9)
     assert float(outs[0][-1].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("hidden,B", [([512, 512, 256], 4096), ([512, 256, 128], 1000), ([512, 128], 96), ([1024, 512], 300)])
+def test_td_in_forward_matches_the_head_backward_launch(dev, hidden, B):
+    """algo.td_in_forward: the critic's fused forward forms the TD error from the Q it has just computed and leaves the head's
+    whole backward (dL/dZ of the last hidden layer, the head's dW / db partials, the loss partials) while that layer's
+    activations are still in LDS, instead of k_skinny_bwd<1, CH, true> re-reading them in a launch of its own.  Per element
+    the same arithmetic: dL/dZ and with it the gradient of every hidden layer are BIT-equal after the first step; the head's
+    own dW / db and the loss add their per-block partials in other groups (64- or 32-row tiles instead of 32-row blocks) and
+    agree to 1e-5 relative; three steps on, parameters agree to that order.  Full, ragged and tiny batches; 64- and 32-row tiles."""
+    from pql_amd.algo.pql_v_learner import PQLVLearner
+    from pql_amd.models.mlp import TanhMLPPolicy
+    O, A, cap = 88, 16, 8000
+    actor = TanhMLPPolicy((O,), A, hidden_layers=hidden).to(dev)
+    actor.load_state_dict(_sd(dd.mlp_state(O, A, 63, tuple(hidden))))
+    outs = []
+    for fwd in (True, False):
+        cfg = make_cfg(False, B=B, memory=cap, hidden=hidden)
+        cfg.algo.td_in_forward = fwd
+        v = PQLVLearner((O,), A, cfg)
+        v.critic.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 61, tuple(hidden))))
+        v.critic_target.arena.data.copy_(v.critic.arena.data)
+        data = tuple(t.to(dev) for t in _fill(O, A, cap - 7, 377))
+        norm = (T(dd.uniform((O,), 831, -0.5, 0.5)).to(dev), T(dd.uniform((O,), 832, 0.5, 2.0)).to(dev), 1e-4)
+        v.update(actor, data, norm, 0)
+        v.learn(indices=T(dd.integers((B,), 940, cap - 7)), noise=T(dd.uniform((B, A), 990, -2, 2)))
+        torch.cuda.synchronize()
+        assert (v._ws["td_fwd"] > 0) is fwd and v._ws["td_parts"] > 0
+        g1, lay = v._ws["grads"].clone(), v.critic.layout
+        for s in range(1, 3):
+            v.learn(indices=T(dd.integers((B,), 940 + s, cap - 7)), noise=T(dd.uniform((B, A), 990 + s, -2, 2)))
+        torch.cuda.synchronize()
+        outs.append((g1, v.critic.arena.data.clone(), v.loss_ring.clone(), lay))
+    (ga, pa, la, lay), (gb, pb, lb, _) = outs
+    nl = lay.n_layers
+    for n in range(2):
+        for l in range(nl - 1):
+            assert torch.equal(lay.weight(ga, n, l), lay.weight(gb, n, l)) and torch.equal(lay.bias(ga, n, l), lay.bias(gb, n, l)), (n, l)
+        wa, wb = lay.weight(ga, n, nl - 1), lay.weight(gb, n, nl - 1)
+        torch.testing.assert_close(wa, wb, rtol=1e-5, atol=1e-6 * float(wb.abs().max()))
+        torch.testing.assert_close(lay.bias(ga, n, nl - 1), lay.bias(gb, n, nl - 1), rtol=1e-5, atol=1e-8)
+        assert float(wb.abs().max()) > 0
+    torch.testing.assert_close(la, lb, rtol=1e-6, atol=1e-9)
+    torch.testing.assert_close(pa, pb, rtol=1e-4, atol=2e-6)
+    assert float(la.abs().sum()) > 0
 
 
 @pytest.mark.parametrize("graph", [False, True])
