@@ -432,7 +432,7 @@ def cpu_baseline(args, O, A, hidden):
     # the GPU box gives one-GPU jobs a 16-core share; more threads than cores makes MKL crawl
     cores = int(os.environ.get("PQL_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
     torch.set_num_threads(cores)
-    B, N, cap = args.batch, args.num_envs, min(args.replay, 200_000)   # smaller resident ring: CPU RAM/time bound
+    B, N, cap = args.batch, args.num_envs, min(args.replay, 5_000_000)   # the GPU run's ring size (cfg #2: 1 M rows = 0.8 GB of host memory per copy)
     g = torch.Generator().manual_seed(0)
     dims_a = ref.layer_dims(O, A, hidden)
     dims_c = ref.layer_dims(O + A, 51 if args.distl else 1, hidden)
