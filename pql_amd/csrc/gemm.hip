@@ -551,7 +551,7 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
   // accumulators one store instruction touches 32 rows x 32 B (and the ELU' operand comes in the same way), i.e. quarter
   // lines; staged through the (now idle) pipeline stages, each wave re-reads its 32 x WN patch row by row and one
   // instruction moves 64 / (WN / 4) whole row segments of WN x 4 B (256 B at WN = 64): full 128-B lines both ways.
-  // The patch is private to the wave (rows wm.., columns wn..), so the two barriers per pass only order LDS reuse.
+  // The patch is private to the wave (rows wm.., columns wn..): no block barrier inside the passes.
   if (MODE != MODE_FWD && EPI != EPI_DTANH_SLICE) {
     const bool whole = (m0 + BM <= p.M) && (n0 + BN <= p.N) && (MODE == MODE_DW || !p.C2);
     if (whole) {   // block-uniform
@@ -595,7 +595,11 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
           for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(patch + r * PLD + 32 * j + 8 * q + 4 * h) =
                 make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-        __syncthreads();
+        // no block barrier: the patch is this wave's own and a wave's LDS instructions execute in order (the k loop ended on a
+        // barrier, so nobody still reads the stages underneath); the four waves drain their passes independently
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int it = 0; it < 32 / RPI; ++it) {
           const int rr = it * RPI + prow;
@@ -611,7 +615,11 @@ __device__ __forceinline__ void gemm_body(const GemmP& p, int bx, int by, int bz
           }
           *reinterpret_cast<float4*>(Cw + grow * p.ldc + gcol) = v;
         }
-        if (i + 1 < MI) __syncthreads();
+        if (i + 1 < MI) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
       }
       if (MODE == MODE_DW && bx == 0 && tid < BM && p.dbias) {
         float* db = p.dbias + (long long)g0 * p.sBias + (long long)split * p.sSplit;
