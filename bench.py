@@ -228,8 +228,10 @@ class Schedule:
 
 
 def gemm_section_ms(v, iters=20):
-    """Device time of the fp32-MFMA GEMM launches of ONE V-learner step (actor fwd + target twin fwd + twin fwd +
-    twin bwd), measured with HIP events on the stream they are launched on (torch's current stream)."""
+    """Device time of the forward + backward launches of ONE V-learner step -- the learner's own calls: actor forward, target
+    twin forward, twin forward (with the Q head's backward inside), the five backward GEMMs and the slab sum that closes the
+    backward call (the one non-MFMA launch in the interval, ~11 us: the fraction is that much conservative) -- measured with HIP
+    events on the stream they are launched on (torch's current stream)."""
     from pql_amd import _lib as L
     import ctypes as C
     ws = v._workspace(int(v.cfg.algo.batch_size))
@@ -244,6 +246,14 @@ def gemm_section_ms(v, iters=20):
         mlp_forward_raw(al, v.actor.arena.data, ws["xn_sa"] if fused_actor else ws["xn_obs"], L.ACT_TANH_NOISE, ws["draw"], 0.8, 0.2,
                         ws["acts_a"], ws["xn_sa"][:, O:], packed=v.pk_actor, stash_all=False)
         mlp_forward_raw(cl, v.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"], packed=v.pk_target, stash_all=False)
+        if ws.get("td_fwd", 0) > 0:   # the learner's own pair of calls: the Q head's backward rides in the critic's forward launch
+            L.check(L.lib.pqlk_mlp_forward_td(C.byref(cl.desc), L.ptr(v.critic.arena.data), L.ptr(v.pk_critic.tensor), L.ptr(ws["x_sa"]), ws["ld_sa"],
+                                              B, L.ptr(ws["acts_c"]), L.ptr(ws["acts_t"]), L.ptr(ws["rew"]), L.ptr(ws["done"]), 0.97,
+                                              L.ptr(ws["scratch"]), L.ptr(ws["bwd"]), ws["bwd"].numel(), ws["splits"], st()))
+            L.check(L.lib.pqlk_mlp_backward_td_tail(C.byref(cl.desc), L.ptr(v.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
+                                                    L.ptr(ws["acts_c"]), L.ptr(ws["grads"]), ws["splits"], L.ptr(ws["bwd"]), ws["bwd"].numel(),
+                                                    None, None, st()))
+            return
         mlp_forward_raw(cl, v.critic.arena.data, ws["x_sa"], L.ACT_NONE, acts=ws["acts_c"], packed=v.pk_critic, stash_all=True)
         L.check(L.lib.pqlk_mlp_backward(C.byref(cl.desc), L.ptr(v.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
                                         L.ptr(ws["acts_c"]), L.ptr(ws["dy"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0, 0,
@@ -663,7 +673,7 @@ def main():
         # roofline of the dominant kernel family: the fp32-MFMA GEMMs of one V step (k_gemm<...>)
         ms = gemm_section_ms(v)
         achieved = f_v / (ms * 1e-3) / 1e12
-        line["roofline"] = {"bound": "mfma", "kernel": "k_gemm + k_mlp_fwd_fused (all fp32 v_mfma_f32_32x32x2 launches of one V-learner step)",
+        line["roofline"] = {"bound": "mfma", "kernel": "k_gemm + k_mlp_fwd_fused (all fp32 v_mfma_f32_32x32x2 launches of one V-learner step, and the slab sum that ends the backward call)",
                             "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic.get("mfma_family_per_v_step_bytes"),
                             "traffic_source": (f"committed profile {traffic_src}, NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / "

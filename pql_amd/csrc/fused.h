@@ -255,6 +255,18 @@ __device__ __forceinline__ void fused_head(const FusedP& p, const float* __restr
   // head, which still needs the activations: there they go into the 256 columns to the right of them (float x of the partial
   // area sits in row x / 256; the host checked buf_ld - Kh >= 256, and 32 R rows x 256 = the NW x R x 1024 floats needed).
   const bool td = TDH && p.td_dz != nullptr;
+  // TD inputs of the rows whose Q this thread will hold (head_ld = 32 columns per row -> thread tid owns column tid % 32 of rows
+  // (tid + 512 k) / 32): requested here, ahead of the partial-tile round trip, so that their latency is not the kernel's tail
+  constexpr int TDI = 2 * R;
+  float tdt[TDI], tdr[TDI], tdd[TDI];
+  if (td && ((wave * 64 + lane) & 31) == 0) {
+#pragma unroll
+    for (int k = 0; k < TDI; ++k) {
+      const long long m = min(row0 + ((wave * 64 + lane) >> 5) + 16 * k, p.B - 1);
+      tdt[k] = fminf(p.td_qt[m * p.head_ld], p.td_qt[((long long)p.B + m) * p.head_ld]);
+      tdr[k] = p.td_rew[m]; tdd[k] = p.td_done[m];
+    }
+  }
   auto part_at = [&](int x) { return td ? (x >> 8) * p.buf_ld + Kh + (x & 255) : x; };
   __syncthreads();   // every wave is done reading the activations
 #pragma unroll
@@ -265,7 +277,8 @@ __device__ __forceinline__ void fused_head(const FusedP& p, const float* __restr
   const float* bias = params + (long long)net * p.net_stride + p.head_b_off;
   float* out = acts + p.head_a_off + (long long)net * p.B * p.head_ld;
   const int tdbase = 32 * R * p.buf_ld;   // TD: [0, 32 R) 2/B (Q - y) per row, [32 R, 64 R) (Q - y)^2; over the bias table (no longer read)
-  for (int o = wave * 64 + lane; o < 32 * R * p.head_ld; o += 64 * NW) {
+  int ok = 0;   // trip count (TD: indexes the inputs requested above)
+  for (int o = wave * 64 + lane; o < 32 * R * p.head_ld; o += 64 * NW, ++ok) {
     const int row = o / p.head_ld, c = o - row * p.head_ld;
     if (row0 + row >= p.B) {
       if (td && c == 0) { fsm[tdbase + row] = 0.f; fsm[tdbase + 32 * R + row] = 0.f; }
@@ -279,9 +292,11 @@ __device__ __forceinline__ void fused_head(const FusedP& p, const float* __restr
       for (int w = 0; w < NW; ++w) s += fsm[part_at(((w * R + i) * 16 + e) * 64 + ln)];
       x = s + bias[c];
       if (td) {   // N == 1: this thread holds Q(row) of this block's net.  y = r + (1-d) gamma^n min Q'  (pql_v_learner.py:104-108)
-        const long long m = row0 + row;
-        const float t1 = p.td_qt[m * p.head_ld], t2 = p.td_qt[((long long)p.B + m) * p.head_ld];
-        const float y = p.td_rew[m] + ((1.f - p.td_done[m]) * p.td_gamma_n) * fminf(t1, t2);
+        float tq = tdt[0], tr = tdr[0], tn = tdd[0];
+#pragma unroll
+        for (int k = 1; k < TDI; ++k)
+          if (ok == k) { tq = tdt[k]; tr = tdr[k]; tn = tdd[k]; }   // (compile-time indices: a runtime one would push the arrays to scratch)
+        const float y = tr + ((1.f - tn) * p.td_gamma_n) * tq;
         const float dq = x - y;
         fsm[tdbase + row] = p.td_two_over_b * dq;
         fsm[tdbase + 32 * R + row] = dq * dq;
@@ -305,32 +320,28 @@ __device__ __forceinline__ void fused_head(const FusedP& p, const float* __restr
   const int kq = Kh >> 2;
   const int tile = row0 / (32 * R);
   float* dz = p.td_dz + ((long long)net * p.B + row0) * Kh;
-  for (int e0 = wave * 64 + lane; e0 < 32 * R * kq; e0 += 64 * NW) {
-    const int row = e0 / kq, q = e0 - row * kq;
-    const float4 h4 = lds4[row * buf_ld4 + q];
-    const float4 w4 = *reinterpret_cast<const float4*>(W + 4 * q);
-    const float dn = fsm[tdbase + row];
-    float4 a = make_float4(dn * w4.x, dn * w4.y, dn * w4.z, dn * w4.w);
-    a.x = h4.x > 0.f ? a.x : a.x * (h4.x + 1.f);   // ELU'(x) = elu(x) + 1 for x <= 0
-    a.y = h4.y > 0.f ? a.y : a.y * (h4.y + 1.f);
-    a.z = h4.z > 0.f ? a.z : a.z * (h4.z + 1.f);
-    a.w = h4.w > 0.f ? a.w : a.w * (h4.w + 1.f);
-    if (row0 + row < p.B) *reinterpret_cast<float4*>(dz + (long long)row * Kh + 4 * q) = a;
-  }
-  // dW partial: wave w sums its 4 R rows for every column quad (lane = quad, chunks of 64 quads), parks the sum in the free
-  // columns of row w, and the block's first waves add the eight in wave order
+  // wave w takes rows [w RW, (w + 1) RW), lane = column quad (chunks of 64 quads): ONE read of h serves dZ (a 1-KiB row segment per
+  // store instruction) and the dW partial, which the wave sums over its rows in ascending order, parks in the free columns of
+  // row w, and wave 0 adds over the eight waves in wave order
   constexpr int RW = 32 * R / NW;
   float* hp = p.td_head_part + ((long long)tile * p.n_nets + net) * p.td_part_floats;
   for (int q0 = 0; q0 < kq; q0 += 64) {
     const int q = q0 + lane;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (q < kq) {
+      const float4 w4 = *reinterpret_cast<const float4*>(W + 4 * q);
 #pragma unroll
       for (int u = 0; u < RW; ++u) {
         const int row = wave * RW + u;
         const float dn = fsm[tdbase + row];
         const float4 h4 = lds4[row * buf_ld4 + q];
         s.x += dn * h4.x; s.y += dn * h4.y; s.z += dn * h4.z; s.w += dn * h4.w;
+        float4 a = make_float4(dn * w4.x, dn * w4.y, dn * w4.z, dn * w4.w);
+        a.x = h4.x > 0.f ? a.x : a.x * (h4.x + 1.f);   // ELU'(x) = elu(x) + 1 for x <= 0
+        a.y = h4.y > 0.f ? a.y : a.y * (h4.y + 1.f);
+        a.z = h4.z > 0.f ? a.z : a.z * (h4.z + 1.f);
+        a.w = h4.w > 0.f ? a.w : a.w * (h4.w + 1.f);
+        if (row0 + row < p.B) *reinterpret_cast<float4*>(dz + (long long)row * Kh + 4 * q) = a;
       }
     }
     __syncthreads();   // (the previous chunk's sums have been folded)
@@ -346,11 +357,10 @@ __device__ __forceinline__ void fused_head(const FusedP& p, const float* __restr
       *reinterpret_cast<float4*>(hp + 4 * q) = t;
     }
   }
-  if (wave == 1 && lane < 32) {   // db (+ the zero pad of the bias block) and the loss partial: rows in ascending order
-    float db = 0.f, ls = 0.f;
-    if (lane == 0)
-      for (int row = 0; row < 32 * R; ++row) { db += fsm[tdbase + row]; ls += fsm[tdbase + 32 * R + row]; }
-    hp[Kh + lane] = lane == 0 ? db : 0.f;
+  if (wave == 1) {   // db (+ the zero pad of the bias block) and the loss partial: lane = row, then the fixed xor-shuffle tree
+    float db = lane < 32 * R ? fsm[tdbase + lane] : 0.f, ls = lane < 32 * R ? fsm[tdbase + 32 * R + lane] : 0.f;
+    db = wave_sum(db); ls = wave_sum(ls);   // (one lane walking the 32 R rows serially was 128 dependent LDS reads at the block's tail: +4 us)
+    if (lane < 32) hp[Kh + lane] = lane == 0 ? db : 0.f;
     if (lane == 0) p.td_loss_part[(long long)tile * p.n_nets + net] = ls;
   }
 }

@@ -40,13 +40,13 @@ def main():
     batches = int(sys.argv[4]) if len(sys.argv) > 4 else 8
     ft, fc = per_kernel(fetch_csv, "FETCH_SIZE")
     wt, wc = per_kernel(write_csv, "WRITE_SIZE")
-    # MFMA launch groups in the trace = V steps (warm-up, timed and the graph captures' dry runs): each runs the three fused
-    # forwards (target actor, target critic, critic) + one critic backward, whose Q-head pass `k_skinny_bwd<1, ...>` no other
-    # component launches (the rollout's policy forward of set-up is a fused launch too; its ~40 launches of 4096 rows stay in the
-    # family total: < 1 % of it)
+    # MFMA launch groups in the trace = V steps (warm-up, timed and the graph captures' dry runs) = launches of the optimiser kernel:
+    # a --v-only run prepares and steps the V-learner only.  Each step runs the three fused forwards (target actor, target critic,
+    # critic -- the last one carries the Q head's backward since round 3) + the critic backward's five GEMMs (the rollout's policy
+    # forward of set-up is a fused launch too; its ~40 launches of 4096 rows stay in the family total: < 1 % of it)
     def groups(calls):
-        n = sum(c for k, c in calls.items() if "k_skinny_bwd<1," in k)
-        assert n, "no Q-head backward launch in the trace"
+        n = sum(c for k, c in calls.items() if k.startswith("k_adamw"))
+        assert n, "no optimiser launch in the trace"
         return n
     v_steps_f, v_steps_w = groups(fc), groups(wc)
     mf_f, _ = family(ft, fc, MFMA)

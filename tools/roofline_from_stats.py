@@ -45,7 +45,7 @@ def main():
     per_batch = B * ((2 * O + A) * 4 + 4 + 1 + 8 + (2 * O + A) * 4 + 4 + 4)
     # (name prefix, label, unit work per V step, kind)
     table = [
-        ("void k_mlp_fwd_fused<2, 2>", "twin-critic fused forward (target + current)", 2 * (2.0 * B * 2 * macs(crit)), "flop"),
+        ("void k_mlp_fwd_fused<2, 2>", "twin-critic fused forward (target + current; round 3: the current one also runs the Q head's backward)", 2 * (2.0 * B * 2 * macs(crit)), "flop"),
         ("void k_mlp_fwd_fused<1, 2>", "actor fused forward (+tanh, target noise)", 2.0 * B * macs(actor), "flop"),
         ("void k_gemm<1, 128, 128", "dX GEMMs (+ELU') of hidden layers 3 and 2, both nets", 2.0 * B * 2 * (h[2] * h[1] + h[1] * h[0]), "flop"),
         ("void k_gemm<2, 128, 128", "dW GEMMs of hidden layers 3 and 2, both nets (16 batch splits)",
