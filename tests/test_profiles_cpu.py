@@ -46,8 +46,8 @@ def test_reducers_read_the_committed_rocprof_files():
     assert rows and 0.5 < float(rows[0].split("|")[-2]) < 0.95
     # Launches per V step straight from the trace's call counts (the kernel-trace runs of tools/profile_bench.sh launch nothing but
     # set-up, warm-up and timed steps): one optimiser launch per step; per step TWO twin-critic fused forwards (target + online),
-    # two dX and two dW products on 128 x 128 tiles, one layer-1 dW product, one head backward (which carries the TD loss: no
-    # loss launch), one slab reduction; ONE replay gather and ONE draw launch per 8 steps; no ATen RNG launch per step.
+    # two dX and two dW products on 128 x 128 tiles, one layer-1 dW product, NO head backward and no loss launch (both ride in the
+    # online critic's forward), one slab reduction; ONE replay gather and ONE draw launch per 8 steps; no ATen RNG launch per step.
     calls = {r["Name"]: int(r["Calls"]) for r in csv.DictReader(open(stats))}
     count = lambda prefix: sum(c for n, c in calls.items() if n.startswith(prefix))   # noqa: E731
     steps = count("k_adamw")
@@ -55,7 +55,8 @@ def test_reducers_read_the_committed_rocprof_files():
     assert steps >= line["steps"] + line["warmup"] and steps <= line["steps"] + line["warmup"] + 16   # + the captures' warm-up runs
     assert count("void k_mlp_fwd_fused<2, 2>") == 2 * steps
     assert count("void k_gemm<1, 128, 128") == 2 * steps and count("void k_gemm<2, 128, 128") == 2 * steps
-    assert count("void k_gemm<2, 64, 64") == steps and count("void k_skinny_bwd<1, 1, true>") == steps
+    assert count("void k_gemm<2, 64, 64") == steps
+    assert count("void k_skinny_bwd<1,") == 0    # (the Q head's backward rides in the critic's forward launch: 10 launches per step)
     assert count("k_reduce_slabs") == steps and count("k_td_mse") == 0
     assert steps // 8 <= count("void k_replay_gather_fast") <= steps // 8 + 3
     assert steps // 8 <= count("k_philox_draws") <= steps // 8 + 4
