@@ -295,6 +295,23 @@ def test_c_abi_reports_argument_errors_as_codes():
     assert lib.pqlk_mlp_backward_td(C.byref(d1), P, P, 32, 4, P, P, P, P, 0.97, P, P, 1, P, 1 << 20, None, None, None) == E_UNSUPPORTED  # one net
     assert lib.pqlk_td_head_loss_parts(C.byref(d), 8192) == 512 and lib.pqlk_td_head_loss_parts(C.byref(d1), 8192) == 0
     assert lib.pqlk_td_head_loss_parts(C.byref(L.mlp_desc([8, 64, 51], 2)), 8192) == 0                                    # C51 heads: own loss kernel
+    # the head's backward inside the critic's forward launch: which layouts take it (no GPU call: eligibility + argument checks)
+    parts = lambda dims, b, nets=2: lib.pqlk_td_forward_loss_parts(C.byref(L.mlp_desc(dims, nets)), b)   # noqa: E731
+    assert parts([104, 512, 512, 256, 1], 8192) == 256        # cfg #2: 128 tiles of 64 rows x 2 nets
+    assert parts([104, 512, 256, 128, 1], 1000) == 64         # reference default widths, ragged batch: 32 tiles of 32 rows x 2
+    assert parts([129, 1024, 512, 1], 300) == 20              # 1024-wide layer: 32-row tiles
+    assert parts([104, 512, 512, 512, 1], 8192) == 0          # no 256 free LDS columns beside the last hidden layer
+    assert parts([104, 256, 256, 1], 96) == 0 and parts([104, 512, 256, 1], 512, nets=1) == 0 and parts([229, 512, 256, 51], 512) == 0
+    assert parts([48, 100, 36, 1], 64) == 0                   # widths not multiples of 32: no fused stack
+    dq = L.mlp_desc([104, 512, 512, 256, 1], 2)
+    ft, tail = lib.pqlk_mlp_forward_td, lib.pqlk_mlp_backward_td_tail
+    assert ft(C.byref(dq), P, None, P, 128, 64, P, P, P, P, 0.97, P, P, 1 << 40, 16, None) == E_NULL       # needs the packed copy
+    assert ft(C.byref(dq), P, P, P, 100, 64, P, P, P, P, 0.97, P, P, 1 << 40, 16, None) == E_ALIGN         # ldx % 32
+    assert ft(C.byref(dq), P, P, P, 128, 64, P, P, P, P, 0.97, P, P, 1024, 16, None) == WS                 # backward workspace too small
+    assert ft(C.byref(d1), P, P, P, 32, 64, P, P, P, P, 0.97, P, P, 1 << 40, 16, None) == E_UNSUPPORTED    # one net
+    assert tail(C.byref(dq), P, P, 128, 64, P, None, 16, P, 1 << 40, None, None, None) == E_NULL           # no gradient arena
+    assert tail(C.byref(dq), P, P, 128, 64, P, P, 16, P, 1 << 40, P, None, None) == E_NULL                 # sumsq without step
+    assert tail(C.byref(d1), P, P, 32, 64, P, P, 16, P, 1 << 40, None, None, None) == E_UNSUPPORTED
     # data-parallel buckets: layer ranges are checked before anything is launched
     bl = lib.pqlk_mlp_backward_layers
     assert bl(C.byref(d), P, P, 32, 4, P, P, None, None, None, 0.97, None, P, 1, P, 1 << 20, 2, 0, None) == E_RANGE      # 2 layers: 0..1
