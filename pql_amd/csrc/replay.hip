@@ -303,14 +303,29 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
   const bool pad_vec = (sa_cols & 3) == 0 && (L.O & 3) == 0;
 
   const int hs = halves - 1;   // 0 or 1: a shift, not a 64-bit division (which cost the 8192-row launch 0.3 us)
-  const int64_t wave = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) >> hs;
+  // (readfirstlane: the wave's row numbers are provably uniform, so the index loads below are scalar loads -- their own counter,
+  //  nothing to do with the in-order vector-memory queue the record loads and the tile stores share)
+  const int64_t wave = ((int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) >> hs;
   const int64_t nwaves = ((int64_t)gridDim.x * 4) >> hs;
+  // The sample indices run ONE trip ahead of the records they address: idx -> record -> store is a dependent chain per trip, and
+  // a wave of the K-batch launch makes five or six trips (65 536 rows over 1536 blocks): the index latency of every trip but the
+  // first now passes under the previous trip's record loads and stores.
+  int64_t nsrc[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) nsrc[i] = wave * R + i < b ? idx[wave * R + i] : 0;
   for (int64_t r0 = wave * R; r0 < b; r0 += nwaves * R) {
     float4 v[R];
+    int64_t srcs[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) srcs[i] = nsrc[i];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
-      const int64_t r = r0 + i;
-      int64_t src = r < b ? idx[r] : 0;
+      const int64_t rn = r0 + nwaves * R + i;
+      nsrc[i] = rn < b ? idx[rn] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      int64_t src = srcs[i];
       if (src < 0 || src >= capacity) src = 0;
       if (cl < nchunk) {
         if (nt_loads) {   // records are read once per sample: keep them out of the caches the output tiles will be read from
@@ -418,7 +433,7 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
   if (fast) {
     // rows in flight per wave: 2 up to 16 Ki rows (more waves, shorter dependent idx -> row chain: 9.3 vs 10.5 us at 8192),
     // 4 beyond (same time at 32 Ki rows, fewer blocks)
-    // 2 rows in flight per wave, at most 24 resident waves per CU (1536 blocks): beyond that the grid-stride loop takes
+    // 2 rows in flight per wave, at most 12 (rounds 1-2: 24) resident waves per CU: beyond that the grid-stride loop takes
     // further trips.  Measured at cfg 5 (32768 rows x 1 KiB, pads not re-zeroed; tools/bench_gather.py): 24 waves/CU x 2 rows
     // 18.5 us, 16 x 2 19.5, 12 x 2 21.4, 32 x 2 22.3, 16 x 4 20.3, 32 x 4 (one trip per wave, the round-1 shape) 23.0, 8 rows
     // in flight 30; at cfg 2 (8192 rows, one trip whatever the cap) 2 rows per wave 7.1 us vs 8.1 (4) and 9.0 (1).
@@ -431,12 +446,15 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
     // normalising and storing out of the ring, so that no wave ever mixes loads and stores) was built and measured too:
     // 20.2 us at best -- no better than this kernel, i.e. the limit is the memory system's rate for this mix (about 4 TB/s of
     // bytes moved), not the way one wave's loads and stores queue.
+    // Round 3 (the K-batch launches: 65 536 rows at cfg 2, five or more trips per wave): with the sample indices loaded one trip
+    // ahead, as SCALAR loads (k_replay_gather_fast), the optimum moved to 12 waves per CU -- 25.1 us at cfg 2 x 8 against 26.5
+    // at 24 and 31.5 at 8 (before: 35.3 at 12, 27.0 at 24); cfg 4 x 8 54.9-57.0 at 12-32; cfg 5 x 8 flat, 145-148 us at 8-32.
     int R = 2;
     if (tune_R == 1 || tune_R == 2 || tune_R == 4 || tune_R == 8) R = tune_R;
     const int halves = nchunk > 64 ? 2 : 1;   // 1-2 KiB records: two waves per row
     const int rows_blk = 4 / halves * R;
     int64_t fb = (b + rows_blk - 1) / rows_blk;
-    const int wpc = tune_wpc ? tune_wpc : 24;
+    const int wpc = tune_wpc ? tune_wpc : 12;
     if (fb > 256 * (int64_t)wpc / 4) fb = 256 * (int64_t)wpc / 4;
     const dim3 g((unsigned)fb), t(256);
 #define PQLK_GATHER_FAST(NORM, RR) \

@@ -53,7 +53,7 @@ def run(name, iters=30):
 
     print(f"== {name}: O={O} A={A} B={B} rec={rb.ring.rec_ld * 4}B  algorithmic {alg / 1e6:.2f} MB, moved {real / 1e6:.2f} MB")
     for R in (2, 4):
-        for wpc in (12, 16, 24, 32):
+        for wpc in (8, 12, 16, 24, 32):
             for nopad in (0, 1):
                 for nt in (0, 1):
                     flags = 1 | (2 if nopad else 0) | (4 if nt else 0) | (R << 8) | (wpc << 12)   # include/pqlk.h: PQLK_GATHER_*
