@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--dp-buckets", default="auto", choices=["auto", "layer", "one"],
                     help="data parallel: the critic's gradient all-reduce in per-layer buckets issued behind each layer's slab sum, "
                          "as one collective after the whole backward, or auto = layer iff PQL_DP_GRAPH_COLLECTIVE=1 (algo.dp_buckets)")
+    ap.add_argument("--no-run-graph", action="store_true", help="one hipGraph per learner step instead of one per run of steps between two hand-offs (A/B of algo.run_graph)")
     ap.add_argument("--no-td-forward", action="store_true", help="head backward as its own launch instead of inside the critic's forward (A/B of algo.td_in_forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true",
@@ -121,6 +122,7 @@ def build_system(args, rank, world, device, pg, learner_device=None):
     cfg.algo.fused_tail = not getattr(args, "no_fused_tail", False)
     cfg.algo.dp_buckets = getattr(args, "dp_buckets", "auto")
     cfg.algo.td_in_forward = not getattr(args, "no_td_forward", False)
+    cfg.algo.run_graph = not getattr(args, "no_run_graph", False)
     cfg.algo.rng = getattr(args, "rng", "auto")
     cfg.algo.reward_scale = 0.01   # preprocess_cfg's AllegroHand value (common.py:159-170)
     sh = getattr(args, "shard", None)
@@ -201,16 +203,28 @@ class Schedule:
         self.pending = None
         self.critic, self.policy = critic, policy   # newest snapshots handed out by the learners
 
-    def step(self):
-        """Rollout is software-pipelined one slice ahead, like the reference's asynchronous actor: the transitions
-        handed to the learners at slice i were produced (on the rollout queue) while the learners ran slice i-1."""
+    def align(self):
+        """Skip to the next slice boundary without issuing anything (the steps of the current slice were issued, and counted
+        by nobody, when it began): what follows is timed from a boundary."""
+        rr = self.r_env if self.mode != "p_only" else max(self.r_env // self.r_p, 1)
+        self.k = (self.k + rr - 1) // rr * rr
+
+    def step(self, remaining=None):
+        """One V-learner step of the schedule.  Rollout is software-pipelined one slice ahead, like the reference's asynchronous
+        actor: the transitions handed to the learners at slice i were produced (on the rollout queue) while the learners ran
+        slice i-1.  The learner steps of a slice are ISSUED together at its first step (`learn_many`: one hipGraph per learner and
+        slice instead of one per step; same launches in the same order on each learner's queue), the other steps of the slice
+        issue nothing; `remaining` = steps the caller will still make (this one included), so that a block which ends inside a
+        slice issues exactly its own steps."""
         k = self.k
         self.k += 1
-        if self.mode == "v_only":
-            self.v.learn()
-            return
-        if self.mode == "p_only":
-            self.p.learn()
+        r = self.r_env
+        if remaining is None:
+            remaining = r
+        if self.mode in ("v_only", "p_only"):
+            rr = r if self.mode == "v_only" else max(r // self.r_p, 1)
+            if k % rr == 0:
+                (self.v if self.mode == "v_only" else self.p).learn_many(min(rr, remaining))
             return
         if k % self.r_env == 0:
             if self.pending is not None:
@@ -222,9 +236,9 @@ class Schedule:
             p_data, v_data, n = self.actor.explore_env(self.env, self.cfg.algo.horizon_len, random=False)
             self.global_steps += n
             self.pending = (p_data, v_data)
-        self.v.learn()
-        if k % self.r_p == self.r_p - 1:
-            self.p.learn()
+            nv = min(r, remaining)
+            self.v.learn_many(nv)
+            self.p.learn_many(nv // self.r_p)
 
 
 def gemm_section_ms(v, iters=20):
@@ -380,8 +394,15 @@ def free_running(actor, v, p, env, cfg, device, n=160):
             vals.append(per_call * reps / (time.perf_counter() - t0))
         return sorted(vals)[1]
 
-    out["v_grad_steps_per_s"] = rate(v.learn, n)
-    out["p_grad_steps_per_s"] = rate(p.learn, n)
+    # the learners' steps issued the way the default (fixed-ratio) loop issues them -- one run of critic_sample_ratio steps
+    # (critic_sample_ratio / critic_actor_ratio for P) per call, one hipGraph per run -- and one `learn()` call per step, which is
+    # what the free-running threads of algo.async_learners=True make
+    kv = int(cfg.algo.critic_sample_ratio)
+    kp = max(kv // int(cfg.algo.critic_actor_ratio), 1)
+    out["v_grad_steps_per_s"] = rate(lambda: v.learn_many(kv), max(n // kv, 4), per_call=float(kv))
+    out["p_grad_steps_per_s"] = rate(lambda: p.learn_many(kp), max(n // kp, 4), per_call=float(kp))
+    out["v_grad_steps_per_s_one_call_per_step"] = rate(v.learn, n)
+    out["p_grad_steps_per_s_one_call_per_step"] = rate(p.learn, n)
     out["env_steps_per_s"] = rate(lambda: actor.explore_env(env, int(cfg.algo.horizon_len), random=False), max(n // 4, 8),
                                   per_call=float(cfg.num_envs) * int(cfg.algo.horizon_len))
     out["note"] = "each component alone, back to back (no ratio control); not part of `value`"
@@ -585,11 +606,12 @@ def main():
 
     def timed_block():
         """EXACTLY --steps steps between barrier + device synchronisation on both sides; max over ranks."""
+        sched.align()   # (a block starts on a slice boundary: a slice's learner steps are issued at its first step)
         barrier()
         sync_all(*devices)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            sched.step()
+        for i in range(args.steps):
+            sched.step(args.steps - i)
         sync_all(*devices)
         barrier()
         dt = time.perf_counter() - t0
@@ -604,8 +626,8 @@ def main():
         while (time.perf_counter() - t_burn) * 1e3 < args.burn_in_ms:
             gemm_section_ms(v, iters=8)   # scratch workspaces only: parameters, Adam state and rings untouched
         note(f"burn-in {args.burn_in_ms:.0f} ms done")
-    for _ in range(args.warmup):
-        sched.step()
+    for i in range(args.warmup):
+        sched.step(args.warmup - i)
     sync_all(*devices)
     note("warm-up done")
     dt = timed_block()

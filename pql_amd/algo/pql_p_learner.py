@@ -89,6 +89,8 @@ class PQLPLearner:
         self._graph_post = None
         self._graph_key = None
         self._slot_graphs = {}
+        self._run_graph = None   # all K draws-ahead steps of one run in ONE hipGraph (learn_many)
+        self._run_graphs = bool(_cfg_get(cfg.algo, "run_graph", True))
 
     @property
     def memory(self):
@@ -149,7 +151,7 @@ class PQLPLearner:
         want = self._want_ahead()   # draws + gathered tiles of the next K steps (see PQLVLearner._workspace)
         K = self._depth if want else 1
         self._ahead = R.DrawAhead(self.gen, self.device, B, None, K, R.verified(self.device)) if want else None
-        self._slot_graphs = {}
+        self._slot_graphs, self._run_graph = {}, None
         ws["K"] = K
         ws["x_sa_all"] = torch.zeros((K, B, ws["ld_sa"]), **f)
         ws["x_obs_all"] = torch.zeros((K, B, ws["ld_o"]), **f)
@@ -275,7 +277,7 @@ class PQLPLearner:
                 if self.use_graph:
                     key = (B, 0, id(self.critic), self.normalize_tuple is None)
                     if self._graph_key != key:
-                        self._slot_graphs, self._graph, self._graph_post, self._graph_key = {}, None, None, key
+                        self._slot_graphs, self._run_graph, self._graph, self._graph_post, self._graph_key = {}, None, None, None, key
                     if slot not in self._slot_graphs:
                         with H.CAPTURE_LOCK:
                             self._capture(ws, key, slot)
@@ -302,6 +304,60 @@ class PQLPLearner:
         return self.sleep_time
 
     @torch.no_grad()
+    def learn_many(self, n):
+        """`n` consecutive actor steps, exactly what n `learn()` calls do; one whole run of draws-ahead steps replays as ONE
+        hipGraph (see PQLVLearner.learn_many)."""
+        n = int(n)
+        if self.critic is None or n <= 0:
+            return self.sleep_time
+        B = int(self.cfg.algo.batch_size)
+        with self._lock, torch.cuda.device(self.device), self._on_stream():
+            ws = self._workspace(B)
+            if (self.use_graph and self._run_graphs and self._ahead is not None and n == ws["K"] and n > 1 and self._ahead.valid in (0, n)
+                    and (self._ahead.valid == 0 or self._ahead.pos == 0) and self.cur_capacity < (1 << 28)
+                    and (not self.dp or graph_collective_enabled(self.pg))):
+                if self._ahead.valid == 0:
+                    self._prefetch(ws)
+                key = (B, 0, id(self.critic), self.normalize_tuple is None)
+                if self._graph_key != key:
+                    self._slot_graphs, self._run_graph, self._graph, self._graph_post, self._graph_key = {}, None, None, None, key
+                if self._run_graph is None:
+                    with H.CAPTURE_LOCK:
+                        self._capture_run(ws, key)
+                for _ in range(n):
+                    self._ahead.take()
+                self._run_graph.replay()
+                self.update_count += n
+                return self.sleep_time
+        for _ in range(n):
+            self.learn()
+        return self.sleep_time
+
+    def _capture_run(self, ws, key):
+        """All K steps of a run (slot 0 .. K-1, in order) in one hipGraph; the tiles `_prefetch` left are in place."""
+        def run():
+            for slot in range(ws["K"]):
+                self._step_kernels(ws, None, tiles=ws["slots"][slot])
+        snap = [t.clone() for t in self._state()]
+        rng = self._rng_state()
+        s = torch.cuda.Stream(self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            run()   # warm-up outside capture, on a side stream as torch requires
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        for dst, src in zip(self._state(), snap):
+            dst.copy_(src)
+        self.repack()
+        g = self._new_graph()
+        with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
+            run()
+        for dst, src in zip(self._state(), snap):
+            dst.copy_(src)
+        self.repack()
+        self._set_rng_state(rng)
+        self._run_graph, self._graph_key = g, key
+
+    @torch.no_grad()
     def prepare(self):
         """Workspace + hipGraph capture now instead of inside the first `learn()` (side-effect free, see PQLVLearner.prepare)."""
         if self.critic is None:
@@ -311,13 +367,16 @@ class PQLPLearner:
             if self.use_graph and self._ahead is not None and 0 < self.cur_capacity < (1 << 28):
                 key = (ws["B"], 0, id(self.critic), self.normalize_tuple is None)
                 if self._graph_key != key:
-                    self._slot_graphs, self._graph, self._graph_post, self._graph_key = {}, None, None, key
+                    self._slot_graphs, self._run_graph, self._graph, self._graph_post, self._graph_key = {}, None, None, None, key
                 off = self.gen.get_offset()
                 self._prefetch(ws)              # real tiles for the captures' warm-up runs; nothing is consumed
                 for slot in range(ws["K"]):
                     if slot not in self._slot_graphs:
                         with H.CAPTURE_LOCK:
                             self._capture(ws, key, slot)
+                if self._run_graph is None and self._run_graphs and ws["K"] > 1 and (not self.dp or graph_collective_enabled(self.pg)):
+                    with H.CAPTURE_LOCK:
+                        self._capture_run(ws, key)
                 self._drop_ahead()
                 self.gen.set_offset(off)
             elif self.use_graph:

@@ -305,6 +305,8 @@ class PQLVLearner:
         self._graph_post = None
         self._graph_key = None
         self._slot_graphs = {}
+        self._run_graph = None   # all K draws-ahead steps of one run in ONE hipGraph (learn_many)
+        self._run_graphs = bool(_cfg_get(algo, "run_graph", True))
 
     # ------------------------------------------------------------------------------------------
     def start(self):
@@ -359,7 +361,7 @@ class PQLVLearner:
         want = self._want_ahead(B)
         K = self._depth if want else 1
         self._ahead = R.DrawAhead(self.gen, dev, B, (B, A), K, R.verified(dev)) if want else None
-        self._slot_graphs = {}
+        self._slot_graphs, self._run_graph = {}, None
         ws["K"] = K
         ws["x_sa_all"] = torch.zeros((K, B, ws["ld_sa"]), **f)
         ws["xn_sa_all"] = torch.zeros((K, B, ws["ld_sa"]), **f)
@@ -591,7 +593,7 @@ class PQLVLearner:
                 if self.use_graph:
                     key = (B, 0, id(self.actor), self.normalize_tuple is None)
                     if self._graph_key != key:
-                        self._slot_graphs, self._graph, self._graph_post, self._graph_key = {}, None, None, key
+                        self._slot_graphs, self._run_graph, self._graph, self._graph_post, self._graph_key = {}, None, None, None, key
                     if slot not in self._slot_graphs:
                         with H.CAPTURE_LOCK:
                             self._capture(ws, key, slot)
@@ -610,6 +612,62 @@ class PQLVLearner:
                 self._draw_and_step(ws)
             self.update_count += 1   # under the lock: update() reads it together with the device loss ring (free-running threads)
         return self.sleep_time
+
+    def _run_in_one_graph(self, ws, n):
+        """Whether `n` steps from here are one whole run of draws-ahead steps that may replay as ONE hipGraph."""
+        return (self.use_graph and self._run_graphs and self._ahead is not None and n == ws["K"] and n > 1 and self._ahead.valid in (0, n)
+                and (self._ahead.valid == 0 or self._ahead.pos == 0) and self.memory.cur_capacity < (1 << 28)
+                and (not self.dp or graph_collective_enabled(self.pg)))
+
+    @torch.no_grad()
+    def learn_many(self, n):
+        """`n` consecutive gradient steps: exactly what n `learn()` calls do -- the same draws, tiles and launches in the same
+        order on this learner's queue, bit for bit.  When they are one whole run of draws-ahead steps (the critic_sample_ratio
+        steps between two `update()` calls of the fixed-ratio loop, scripts/train_pql.py) they replay as ONE hipGraph instead of
+        one per step: every graph boundary costs the queue ~5 us of device time (tools/probes/multistep_graph_probe.py: 603.8 ->
+        599.0 us per step) and the host a launch.  Anything else (a partial run, per-step draws, eager mode, eager data-parallel
+        collectives) is the loop of `learn()` calls itself."""
+        n = int(n)
+        if self.actor is None or n <= 0:
+            return self.sleep_time
+        B = int(self.cfg.algo.batch_size)
+        with self._lock, torch.cuda.device(self.device), self._on_stream():
+            ws = self._workspace(B)
+            if self._run_in_one_graph(ws, n):
+                if self._ahead.valid == 0:
+                    self._prefetch(ws)
+                key = (B, 0, id(self.actor), self.normalize_tuple is None)
+                if self._graph_key != key:
+                    self._slot_graphs, self._run_graph, self._graph, self._graph_post, self._graph_key = {}, None, None, None, key
+                if self._run_graph is None:
+                    with H.CAPTURE_LOCK:
+                        self._capture_run(ws, key)
+                for _ in range(n):
+                    self._ahead.take()
+                self._run_graph.replay()
+                self.update_count += n
+                return self.sleep_time
+        for _ in range(n):
+            self.learn()
+        return self.sleep_time
+
+    def _capture_run(self, ws, key):
+        """All K steps of a run (slot 0 .. K-1, in order) in one hipGraph; the tiles and draws `_prefetch` left are in place."""
+        def run():
+            for slot in range(ws["K"]):
+                self._step_kernels(ws, None, self._ahead.normal[slot], tiles=ws["slots"][slot])
+        snap = self._snapshot()
+        s = torch.cuda.Stream(self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            run()   # warm-up outside capture, on a side stream as torch requires
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        self._restore(snap)
+        g = self._new_graph()
+        with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
+            run()
+        self._restore(snap)
+        self._run_graph, self._graph_key = g, key
 
     def _replay(self, ws, g):
         """g: the step's hipGraph, or (data parallel, collectives kept eager) the list of its pieces: one graph up to the
@@ -637,13 +695,16 @@ class PQLVLearner:
             if self.use_graph and self._ahead is not None and 0 < self.memory.cur_capacity < (1 << 28):
                 key = (ws["B"], 0, id(self.actor), self.normalize_tuple is None)
                 if self._graph_key != key:
-                    self._slot_graphs, self._graph, self._graph_post, self._graph_key = {}, None, None, key
+                    self._slot_graphs, self._run_graph, self._graph, self._graph_post, self._graph_key = {}, None, None, None, key
                 off = self.gen.get_offset()
                 self._prefetch(ws)              # (the captures' warm-up runs need real tiles; nothing is consumed: the
                 for slot in range(ws["K"]):     #  generator is put back and the tiles are dropped)
                     if slot not in self._slot_graphs:
                         with H.CAPTURE_LOCK:
                             self._capture(ws, key, slot)
+                if self._run_graph is None and self._run_graphs and ws["K"] > 1 and (not self.dp or graph_collective_enabled(self.pg)):
+                    with H.CAPTURE_LOCK:
+                        self._capture_run(ws, key)
                 self._drop_ahead()
                 self.gen.set_offset(off)
             elif self.use_graph:

@@ -143,10 +143,10 @@ def main(cfg):
             if sim_wait > 0:
                 time.sleep(sim_wait)
         else:
-            for k in range(v_per_iter):
-                v_learner.learn()
-                if k % p_every == p_every - 1:
-                    p_learner.learn()
+            # (issued per learner: the steps of one learner between two hand-offs are ONE hipGraph on its queue -- learn_many --
+            #  and the two queues are independent, so this is the interleaved V, V, P, V, V, P ... order as far as results go)
+            v_learner.learn_many(v_per_iter)
+            p_learner.learn_many(v_per_iter // p_every)
         if rank == 0 and evaluator.parent.poll():
             logger.log(evaluator.parent.recv(), global_steps)
         if rank == 0 and iter_t % cfg.algo.log_freq == 0:

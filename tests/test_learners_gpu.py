@@ -374,6 +374,58 @@ def test_td_in_forward_matches_the_head_backward_launch(dev, hidden, B):
     assert float(la.abs().sum()) > 0
 
 
+def test_learn_many_replays_a_whole_run_as_one_graph_with_the_bits_of_the_per_step_calls(dev):
+    """`learn_many(n)` = n `learn()` calls.  With n = the draws-ahead depth at the start of a run (what the fixed-ratio loop issues
+    between two `update()` calls) the steps replay as ONE hipGraph per learner; a run already begun, another n, or per-step draws
+    fall back to the loop of `learn()`.  Same seeds -> bit-identical parameters, Adam state, loss rings and generator offsets
+    against the per-step calls, across updates, for both learners."""
+    from pql_amd.algo.pql_p_learner import PQLPLearner
+    from pql_amd.algo.pql_v_learner import PQLVLearner
+    from pql_amd.models.mlp import TanhMLPPolicy
+    O, A, B = 24, 6, 512
+    res = {}
+    for many in (False, True):
+        cfg = make_cfg(False, B=B, memory=4000, hidden=[256, 128], graph=True)
+        cfg.algo.rng = "auto"
+        v, p = PQLVLearner((O,), A, cfg), PQLPLearner((O,), A, cfg)
+        v.critic.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 21, hidden=(256, 128)))); v.critic_target.arena.data.copy_(v.critic.arena.data)
+        p.actor.load_state_dict(_sd(dd.mlp_state(O, A, 11, hidden=(256, 128))))
+        v.use_private_rng(5); p.use_private_rng(6)
+        from pql_amd.utils import rng as R
+        if R.verified(dev) is None:
+            pytest.skip("pqlk_philox_draws does not reproduce torch's draws on this device: no draws-ahead runs")
+        Kv, Kp = v._depth, p._depth
+        runs_v = runs_p = 0
+        for it in range(4):
+            norm = (T(dd.uniform((O,), 40 + it, -0.5, 0.5)).to(dev), T(dd.uniform((O,), 50 + it, 0.5, 2.0)).to(dev), 1e-4)
+            data = tuple(t.to(dev) for t in _fill(O, A, 700, 100 + it))
+            critic, _, _ = v.update(p.actor, data, norm, 0)
+            p.update(critic, data[0], norm, 0)
+            # iteration 2 issues a PARTIAL run first (3 steps), then the rest: learn_many must fall back to per-step calls there
+            plan_v = [Kv] if it != 2 else [3, Kv - 3]
+            for n in plan_v:
+                if many:
+                    runs_v += v._run_in_one_graph(v._workspace(B), n)
+                    v.learn_many(n)
+                else:
+                    for _ in range(n):
+                        v.learn()
+            if many:
+                p.learn_many(Kp)
+            else:
+                for _ in range(Kp):
+                    p.learn()
+        torch.cuda.synchronize()
+        assert v.update_count == 4 * Kv and p.update_count == 4 * Kp
+        if many:
+            assert runs_v == 3 and v._run_graph is not None and p._run_graph is not None   # three whole runs, one split run
+        res[many] = [t.clone() for t in (v.critic.arena.data, v.critic_target.arena.data, v.opt.m, v.opt.v, v.loss_ring, p.actor.arena.data,
+                                         p.opt.m, p.opt.v, p.loss_ring)] + [torch.tensor([v.gen.get_offset(), p.gen.get_offset()])]
+    for a, b in zip(res[False], res[True]):
+        assert torch.equal(a, b)
+    assert float(res[True][4].abs().sum()) > 0 and float(res[True][8].abs().sum()) > 0
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_draws_ahead_and_batched_gather_equal_the_per_step_torch_draws(dev, graph):
     """algo.rng=auto: the draws of the next K steps come from one pqlk_philox_draws launch and their K x B rows from one gather,
