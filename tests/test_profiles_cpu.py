@@ -52,14 +52,15 @@ def test_reducers_read_the_committed_rocprof_files():
     count = lambda prefix: sum(c for n, c in calls.items() if n.startswith(prefix))   # noqa: E731
     steps = count("k_adamw")
     line = json.load(open(stats.replace("_kernel_stats.csv", "_under_rocprof.json")))
-    assert steps >= line["steps"] + line["warmup"] and steps <= line["steps"] + line["warmup"] + 16   # + the captures' warm-up runs
+    issued = line["steps"] + line["warmup"]
+    assert issued <= steps <= issued + 24   # + the captures' warm-up runs (per-slot graphs, and since the end of round 3 the run graph)
     assert count("void k_mlp_fwd_fused<2, 2>") == 2 * steps
     assert count("void k_gemm<1, 128, 128") == 2 * steps and count("void k_gemm<2, 128, 128") == 2 * steps
     assert count("void k_gemm<2, 64, 64") == steps
     assert count("void k_skinny_bwd<1,") == 0    # (the Q head's backward rides in the critic's forward launch: 10 launches per step)
     assert count("k_reduce_slabs") == steps and count("k_td_mse") == 0
-    assert steps // 8 <= count("void k_replay_gather_fast") <= steps // 8 + 3
-    assert steps // 8 <= count("k_philox_draws") <= steps // 8 + 4
+    assert issued // 8 <= count("void k_replay_gather_fast") <= issued // 8 + 3   # (the captures' dry runs reuse the tiles in place)
+    assert issued // 8 <= count("k_philox_draws") <= issued // 8 + 4
     aten_rng = sum(c for n, c in calls.items() if "distribution_elementwise_grid_stride_kernel" in n)
     assert aten_rng < steps          # (set-up only: ring pre-fill, rollout noise, the start-up check; round 2 had 2 per step on top)
     traffic = json.load(open(_newest("r*_pmc_traffic.json")))
