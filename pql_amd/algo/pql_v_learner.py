@@ -392,6 +392,8 @@ class PQLVLearner:
             ws["td_fwd"] = int(L.lib.pqlk_td_forward_loss_parts(C.byref(cl.desc), B))
             if ws["td_fwd"] > 0:
                 ws["td_parts"] = ws["td_fwd"]
+        if ws["td_parts"] > ws["scratch"].numel():   # (batches past 65 536: one loss partial per row tile and net)
+            ws["scratch"] = torch.zeros(ws["td_parts"], **f)
         if self._buckets is not None:
             ws["bucket_views"] = [DP.bucket_views(ws["grads"], cl, hi, lo) for hi, lo in self._buckets]
         self._ws = ws
