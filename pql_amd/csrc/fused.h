@@ -462,14 +462,19 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
     const float4* packed_n = last ? nullptr : packed_net + (p.p_off[l + 1] >> 2);
     const int K8n = last ? 1 : N >> 3, ntiles_n = last ? 1 : p.dims[l + 2] >> 5;
     const int tpw = tpw_of(ntiles), tpw_n = tpw_of(ntiles_n);
+    // The wide instantiation compiles THREE layer bodies (4, 2, 1 tiles per wave); hipcc hoists the loop-invariant part of all
+    // their epilogue / stash addresses above the layer loop and, at 256 registers, spills it (55 VGPRs, round 3).  An opaque
+    // per-layer copy of the lane id keeps those few integer ops inside the layer they belong to.
+    int lane_l = lane;
+    if (TM >= 4) asm volatile("" : "+v"(lane_l));
     if (TM >= 4 && tpw == 4)
-      fused_layer<R, (TM >= 4 ? 4 : 1), TM, D>(bq, buf_ld4, K8, K8s, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n,
+      fused_layer<R, (TM >= 4 ? 4 : 1), TM, D>(bq, buf_ld4, K8, K8s, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane_l, packed_n, K8n,
                                                ntiles_n, tpw_n, gprev, nprev4);
     else if (tpw == 2)
-      fused_layer<R, 2, TM, D>(bq, buf_ld4, K8, K8s, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n, ntiles_n,
+      fused_layer<R, 2, TM, D>(bq, buf_ld4, K8, K8s, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane_l, packed_n, K8n, ntiles_n,
                                tpw_n, gprev, nprev4);
     else
-      fused_layer<R, 1, TM, D>(bq, buf_ld4, K8, K8s, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane, packed_n, K8n, ntiles_n,
+      fused_layer<R, 1, TM, D>(bq, buf_ld4, K8, K8s, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane_l, packed_n, K8n, ntiles_n,
                                tpw_n, gprev, nprev4);
   }
   if (p.head_n > 0) fused_head<R>(p, pparams, pacts, net, row0, buf_ld4, wave, lane);   // the LDS buffer holds the last hidden layer's output

@@ -790,22 +790,22 @@ static int launch_gemm(GemmP p, int gz, hipStream_t st) {
   constexpr size_t patch_floats = (size_t)4 * 32 * (BN / 2 + 4);   // the epilogue's per-wave staging patches
   const size_t shmem = (stage_floats > patch_floats ? stage_floats : patch_floats) * sizeof(float);
   static PqlkPerDeviceOnce attr_once;
-  if (attr_once.need()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, BM, BN, EPI, KT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return -(int)e;
-  }
+  if (int rc = attr_once.run([&] {
+        return -(int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, BM, BN, EPI, KT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      }))
+    return rc;
   dim3 grid;
   const bool dma = gemm_plan<MODE, BM, BN, EPI>(p, gz, grid);
   if constexpr (KT == 16 && (MODE == MODE_DX || MODE == MODE_DW) && (EPI == EPI_DELU || EPI == EPI_NONE)) {
     if (dma) {
       constexpr size_t dshmem = gemm_dma_lds<BM, BN, KT>();
       static PqlkPerDeviceOnce dma_once;
-      if (dma_once.need()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, BM, BN, EPI, KT, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)dshmem);
-        if (e != hipSuccess) return -(int)e;
-      }
+      if (int rc = dma_once.run([&] {
+            return -(int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<MODE, BM, BN, EPI, KT, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)dshmem);
+          }))
+        return rc;
       hipLaunchKernelGGL((k_gemm<MODE, BM, BN, EPI, KT, true>), grid, dim3(256), dshmem, st, p);
       PQLK_LAUNCH_CHECK();
       return PQLK_OK;
@@ -1046,14 +1046,16 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
   for (int l = 1; l < d->n_layers; ++l) wide = wide || d->dims[l] > 512;
   const int R = fused_rows(d, buf_ld, b);
   static PqlkPerDeviceOnce attr_once;
-  if (attr_once.need()) {
-    const void* ks[3] = {reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 2>), reinterpret_cast<const void*>(&k_mlp_fwd_fused<2, 2>),
-                         reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 4>)};
-    for (const void* k : ks) {
-      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return -(int)e;
-    }
-  }
+  if (int rc = attr_once.run([&] {
+        const void* ks[3] = {reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 2>), reinterpret_cast<const void*>(&k_mlp_fwd_fused<2, 2>),
+                             reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 4>)};
+        for (const void* k : ks) {
+          hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          if (e != hipSuccess) return -(int)e;
+        }
+        return 0;
+      }))
+    return rc;
   const size_t shmem = fused_lds_bytes(d, buf_ld, R);
   dim3 grid((unsigned)(((b + 32 * R - 1) / (32 * R)) * d->n_nets)), block(64 * FUSED_NW);
   if (wide) hipLaunchKernelGGL((k_mlp_fwd_fused<1, 4>), grid, block, shmem, st, p);

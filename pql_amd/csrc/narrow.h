@@ -305,13 +305,15 @@ static bool dx_slice_ok(const GemmP& p) {
 static int launch_dx_slice(const GemmP& p, hipStream_t st) {
   const size_t shmem = dx_slice_lds(p);
   static PqlkPerDeviceOnce attr_once;
-  if (attr_once.need()) {
-    for (const void* k : {reinterpret_cast<const void*>(&k_dx_slice<16>), reinterpret_cast<const void*>(&k_dx_slice<4>),
-                          reinterpret_cast<const void*>(&k_dx_slice<1>)}) {
-      hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return -(int)e;
-    }
-  }
+  if (int rc = attr_once.run([&] {
+        for (const void* k : {reinterpret_cast<const void*>(&k_dx_slice<16>), reinterpret_cast<const void*>(&k_dx_slice<4>),
+                              reinterpret_cast<const void*>(&k_dx_slice<1>)}) {
+          hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          if (e != hipSuccess) return -(int)e;
+        }
+        return 0;
+      }))
+    return rc;
   const int K8 = p.groups * p.K / 32;   // reduction steps of 8 per wave
   const dim3 grid((unsigned)((p.M + 31) / 32)), block(256);
   if (K8 % 16 == 0) hipLaunchKernelGGL(k_dx_slice<16>, grid, block, shmem, st, p);

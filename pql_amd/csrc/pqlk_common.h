@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "../../include/pqlk.h"
 
 #define PQLK_WAVE 64
@@ -50,14 +53,23 @@ __host__ __device__ static inline RecLayout rec_layout(int O, int A) {
 
 // "have I raised this kernel's dynamic-LDS limit on the CURRENT device yet?"  hipFuncSetAttribute acts on the current
 // device only, and one process may drive several (sim on GPU 0, learners on GPU 1): the flag is per device.
+// ctypes drops the GIL, so two host threads (the V and the P learner of `algo.async_learners`) may make a kernel's first call
+// at once: the device is marked done only AFTER the attribute call returned success, and a second caller waits on the mutex
+// until then (never launching with > 64 KB of dynamic LDS before the limit is raised).  The fast path is one acquire load.
 struct PqlkPerDeviceOnce {
-  bool done[64] = {};
-  bool need() {
+  std::atomic<bool> done[64] = {};
+  std::mutex mu;
+  // f() -> 0 on success, else the (negative) error code to hand back; it is run again by the next call after a failure
+  template <class F>
+  int run(F&& f) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-    if (done[dev]) return false;
-    done[dev] = true;
-    return true;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return f();
+    if (done[dev].load(std::memory_order_acquire)) return 0;
+    std::lock_guard<std::mutex> g(mu);
+    if (done[dev].load(std::memory_order_relaxed)) return 0;
+    const int rc = f();
+    if (rc == 0) done[dev].store(true, std::memory_order_release);
+    return rc;
   }
 };
 

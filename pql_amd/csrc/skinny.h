@@ -437,11 +437,11 @@ template <int NB, int CH, bool TD = false>
 static int launch_skinny_bwd_t(const SkinnyP& p, int groups, float* part, long long part_floats, hipStream_t st) {
   const size_t sh = ((size_t)4 * p.N * p.K + 72) * sizeof(float);
   static PqlkPerDeviceOnce attr_once;
-  if (attr_once.need()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skinny_bwd<NB, CH, TD>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (4 * 4096 + 72) * (int)sizeof(float));   // N x K <= 16 x 256 floats
-    if (e != hipSuccess) return -(int)e;
-  }
+  if (int rc = attr_once.run([&] {
+        return -(int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skinny_bwd<NB, CH, TD>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (4 * 4096 + 72) * (int)sizeof(float));   // N x K <= 16 x 256 floats
+      }))
+    return rc;
   hipLaunchKernelGGL((k_skinny_bwd<NB, CH, TD>), dim3(skinny_bwd_blocks(p.M, groups), groups), dim3(256), sh, st, p, part, part_floats,
                      skinny_bwd_rows(p.M, groups));
   PQLK_LAUNCH_CHECK();
@@ -480,11 +480,11 @@ static int launch_skinny_fwd(const SkinnyP& p, int groups, hipStream_t st) {
   if (blocks > 2048) blocks = 2048;
   const size_t sh = (size_t)p.N * p.K * sizeof(float);
   static PqlkPerDeviceOnce attr_once;
-  if (attr_once.need()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skinny_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       SKINNY_MAX_N * SKINNY_MAX_K * 4);
-    if (e != hipSuccess) return -(int)e;
-  }
+  if (int rc = attr_once.run([&] {
+        return -(int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skinny_fwd), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         SKINNY_MAX_N * SKINNY_MAX_K * 4);
+      }))
+    return rc;
   hipLaunchKernelGGL(k_skinny_fwd, dim3(blocks, groups), dim3(256), sh, st, p);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
@@ -495,11 +495,11 @@ static int launch_skinny_dx(const SkinnyP& p, int groups, hipStream_t st) {
   if (blocks > 2048) blocks = 2048;
   const size_t sh = (size_t)p.N * p.K * sizeof(float);
   static PqlkPerDeviceOnce attr_once;
-  if (attr_once.need()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skinny_dx), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       SKINNY_MAX_N * SKINNY_MAX_K * 4);
-    if (e != hipSuccess) return -(int)e;
-  }
+  if (int rc = attr_once.run([&] {
+        return -(int)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_skinny_dx), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         SKINNY_MAX_N * SKINNY_MAX_K * 4);
+      }))
+    return rc;
   hipLaunchKernelGGL(k_skinny_dx, dim3(blocks, groups), dim3(256), sh, st, p);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;

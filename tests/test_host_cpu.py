@@ -468,3 +468,21 @@ def test_bench_refuses_more_gpus_than_visible():
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), *extra], env=env,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+
+
+def test_no_kernel_of_the_library_goes_through_scratch():
+    """Every kernel's own metadata (tools/kernel_resources.py): no spilled VGPR, no private segment.  A spilling kernel stays
+    correct and green everywhere else; round 3's k_mlp_fwd_fused<1,4> (hidden widths > 512) carried 59 spilled registers."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    if not os.path.exists(f"{kr.LLVM}/llvm-readelf"):
+        pytest.skip("no llvm-readelf")
+    res = kr.resources()
+    assert len(res) >= 60
+    for want in ("k_mlp_fwd_fused<1, 2>", "k_mlp_fwd_fused<2, 2>", "k_mlp_fwd_fused<1, 4>", "k_replay_gather_fast<true, 2>", "k_adamw"):
+        assert any(want in k for k in res), want
+    bad = kr.spilling(res)
+    assert not bad, {k: (v.get("vgpr_spill_count"), v.get("private_segment_fixed_size")) for k, v in bad.items()}
+    for k, v in res.items():   # the register file is 512 per SIMD lane: nothing may ask for more than 256 + 256
+        assert v.get("vgpr_count", 0) <= 512 and v.get("max_flat_workgroup_size", 0) <= 1024, k

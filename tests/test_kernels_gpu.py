@@ -975,3 +975,62 @@ def test_philox_draws_are_torchs_own_numbers(dev):
         a2 = R.DrawAhead(g4, dev, B, None, K, contract)
         a2.refill(cap)
         assert torch.equal(a2.idx, torch.stack(wi))
+
+
+def test_first_calls_from_two_threads_at_once(dev):
+    """ctypes drops the GIL: with algo.async_learners the V and P learner threads can make a kernel's FIRST call in the same
+    instant.  The per-device once-flag must not let the second caller launch (with > 64 KB of dynamic LDS) before the first has
+    raised the kernel's limit -- round 3 marked the device done before calling hipFuncSetAttribute.  Run in a fresh process so
+    that the calls really are the first ones."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import ctypes as C, threading, sys, torch
+sys.path.insert(0, %r)
+from pql_amd import _lib as L
+from pql_amd.models.mlp import DoubleQ, PackedWeights, mlp_forward_raw, output_view
+dev = torch.device("cuda:0")
+torch.manual_seed(3)
+q = DoubleQ((88,), 16, hidden_layers=[512, 512, 256]).to(dev)
+lay = q.layout
+pk = PackedWeights(lay, dev)
+B = 4096
+x = torch.zeros(B, L.ld(104), device=dev); x[:, :104].normal_()
+torch.cuda.synchronize()
+streams = [torch.cuda.Stream(dev) for _ in range(2)]
+gate = threading.Barrier(2)
+outs, errs = [None, None], []
+def run(i):
+    try:
+        with torch.cuda.stream(streams[i]):
+            gate.wait()
+            outs[i] = mlp_forward_raw(lay, q.arena.data, x, packed=None).clone()   # per-layer k_gemm launches: the process's first
+    except Exception as e:   # noqa: BLE001
+        errs.append(repr(e))
+ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+[t.start() for t in ts]; [t.join() for t in ts]
+torch.cuda.synchronize()
+assert not errs, errs
+assert torch.equal(outs[0], outs[1])
+pk.refresh(q.arena.data); torch.cuda.synchronize()
+gate2 = threading.Barrier(2)
+def run2(i):
+    try:
+        with torch.cuda.stream(streams[i]):
+            gate2.wait()
+            outs[i] = mlp_forward_raw(lay, q.arena.data, x, packed=pk).clone()   # k_mlp_fwd_fused: 132 KB of dynamic LDS
+    except Exception as e:   # noqa: BLE001
+        errs.append(repr(e))
+ts = [threading.Thread(target=run2, args=(i,)) for i in range(2)]
+[t.start() for t in ts]; [t.join() for t in ts]
+torch.cuda.synchronize()
+assert not errs, errs
+assert torch.equal(outs[0], outs[1])
+ref = mlp_forward_raw(lay, q.arena.data, x, packed=pk); torch.cuda.synchronize()
+assert torch.equal(output_view(lay, ref, B), output_view(lay, outs[0], B))
+print("ok")
+''' % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
