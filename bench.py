@@ -241,11 +241,10 @@ class Schedule:
             self.p.learn_many(nv // self.r_p)
 
 
-def gemm_section_ms(v, iters=20):
-    """Device time of the forward + backward launches of ONE V-learner step -- the learner's own calls: actor forward, target
-    twin forward, twin forward (with the Q head's backward inside), the five backward GEMMs and the slab sum that closes the
-    backward call (the one non-MFMA launch in the interval, ~11 us: the fraction is that much conservative) -- measured with HIP
-    events on the stream they are launched on (torch's current stream)."""
+def v_section(v):
+    """The forward + backward launches of ONE V-learner step as a closure (the learner's own calls, on scratch state: no optimiser
+    step, no parameter changes): actor forward, target twin forward, twin forward (with the Q head's backward inside), the five
+    backward GEMMs and the slab sum that closes the backward call."""
     from pql_amd import _lib as L
     import ctypes as C
     ws = v._workspace(int(v.cfg.algo.batch_size))
@@ -272,6 +271,14 @@ def gemm_section_ms(v, iters=20):
         L.check(L.lib.pqlk_mlp_backward(C.byref(cl.desc), L.ptr(v.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
                                         L.ptr(ws["acts_c"]), L.ptr(ws["dy"]), L.ptr(ws["grads"]), ws["splits"], None, 0, 0, 0,
                                         None, 0, L.ptr(ws["bwd"]), ws["bwd"].numel(), st()))
+    return section
+
+
+def gemm_section_ms(v, iters=20):
+    """Device time of the forward + backward launches of ONE V-learner step (v_section: the slab sum that closes the backward call is
+    the one non-MFMA launch in the interval, ~11 us: the fraction is that much conservative) -- measured with HIP events on the stream
+    they are launched on (torch's current stream)."""
+    section = v_section(v)
 
     with torch.cuda.device(v.device):
         for _ in range(3):
@@ -333,6 +340,7 @@ def gather_ms(v, batches=1, iters=50):
     """Device time of one fused replay gather launch of `batches` x B rows (HIP events, same stream): batches = 1 is the
     per-step launch, batches = K the launch that serves the next K V-learner steps at once (PQLVLearner._prefetch)."""
     from pql_amd import _lib as L
+    from pql_amd.algo.pql_v_learner import GATHER_FLAGS
     import ctypes as C
     ws = v._workspace(int(v.cfg.algo.batch_size))
     B = ws["B"]
@@ -350,7 +358,7 @@ def gather_ms(v, batches=1, iters=50):
     xn_obs = None if fused_actor else torch.zeros((rows, ws["ld_o"]), **f)
 
     def one(i):
-        L.check(L.lib.pqlk_replay_gather_fused(C.byref(v.memory.ring.desc), L.ptr(idx[i]), rows, L.ptr(mean), L.ptr(var), eps, 3,
+        L.check(L.lib.pqlk_replay_gather_fused(C.byref(v.memory.ring.desc), L.ptr(idx[i]), rows, L.ptr(mean), L.ptr(var), eps, GATHER_FLAGS,
                                                L.ptr(x_sa), ws["ld_sa"], L.ptr(xn_sa), L.ptr(xn_obs), ws["ld_o"],
                                                L.ptr(rew), L.ptr(done), L.stream(v.device)))
     with torch.cuda.device(v.device):
@@ -374,6 +382,111 @@ def gather_ms(v, batches=1, iters=50):
         e1.record()
         e1.synchronize()
         return e0.elapsed_time(e1) / iters
+
+
+def _graph_of(fn, device):
+    """hipGraph of `fn()` (warm-up on a side stream first, as torch requires)."""
+    side = torch.cuda.Stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream(device).wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        fn()
+    return g
+
+
+def _replay_ms(g, reps=5):
+    """Median HIP-event time of `reps` replays of a graph."""
+    g.replay()
+    out = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        out.append(e0.elapsed_time(e1))
+    return sorted(out)[len(out) // 2]
+
+
+def isolated_launch_ms(launch, device, n=16, sets=4, context=None, evict_mb=384):
+    """Device time of ONE launch the way the schedule pays for it: alone, with other work between two launches of the kernel.
+    `launch(i, s)` issues the launch with index row i into output-tile set s; `context()` issues the work that separates two launches
+    -- the learner step's own kernels (the gather of the schedule runs once per K steps, behind a step's backward and optimiser
+    launches, with the caches full of THEIR data) -- default: a read sweep over `evict_mb` MB (more than L2 + the 256-MB Infinity
+    Cache; reads, so the caches are left full of CLEAN lines: behind a 384-MB WRITE sweep the same gather reads 40 us, because
+    every line it allocates first pushes a dirty line out -- tools/probes/gather_limit_probe.hip).  Two hipGraphs are timed with HIP
+    events on the stream they run on -- n x [context, launch] and n x [context] -- and the difference / n is the launch.  Replayed
+    back to back (50 launches into one set of output tiles, which then lives in the Infinity Cache) the same kernel reads ~15 %
+    faster: that figure is reported as `frac_back_to_back`.  Consecutive launches write `sets` distinct output-tile sets."""
+    if context is None:
+        evict = torch.zeros(evict_mb * (1 << 20) // 4, dtype=torch.float32, device=device)
+        sink = torch.zeros(1, dtype=torch.float32, device=device)
+
+        def context():
+            torch.sum(evict, out=sink[0])
+
+    def with_launch():
+        for i in range(n):
+            context()
+            launch(i, i % sets)
+
+    def without():
+        for _ in range(n):
+            context()
+
+    with torch.cuda.device(device):
+        ga, gb = _graph_of(with_launch, device), _graph_of(without, device)
+        # interleaved replays: clock / thermal drift hits both graphs alike
+        ta, tb = [], []
+        for _ in range(5):
+            ta.append(_replay_ms(ga, 1))
+            tb.append(_replay_ms(gb, 1))
+        ta.sort(); tb.sort()
+    return (ta[2] - tb[2]) / n
+
+
+def gather_isolated_ms(v, batches, n=16, sets=4, in_step=True):
+    """The V-learner's K-batch replay gather as ONE isolated launch (see isolated_launch_ms): between two launches, the forward +
+    backward launches of a V step (`in_step`, what the schedule does) or the clean read sweep."""
+    from pql_amd import _lib as L
+    from pql_amd.algo.pql_v_learner import GATHER_FLAGS
+    import ctypes as C
+    ws = v._workspace(int(v.cfg.algo.batch_size))
+    rows = batches * ws["B"]
+    mean, var, eps = v._norm_ptrs()
+    idx = torch.randint(v.memory.cur_capacity, size=(n, rows), device=v.device)
+    fused_actor = v.pk_actor is not None and v.pk_actor.tensor is not None
+    f = dict(dtype=torch.float32, device=v.device)
+    tiles = [dict(x_sa=torch.zeros((rows, ws["ld_sa"]), **f), xn_sa=torch.zeros((rows, ws["ld_sa"]), **f), rew=torch.zeros(rows, **f),
+                  done=torch.zeros(rows, **f), xn_obs=None if fused_actor else torch.zeros((rows, ws["ld_o"]), **f)) for _ in range(sets)]
+
+    def launch(i, s):
+        t = tiles[s]
+        L.check(L.lib.pqlk_replay_gather_fused(C.byref(v.memory.ring.desc), L.ptr(idx[i]), rows, L.ptr(mean), L.ptr(var), eps, GATHER_FLAGS,
+                                               L.ptr(t["x_sa"]), ws["ld_sa"], L.ptr(t["xn_sa"]), L.ptr(t["xn_obs"]), ws["ld_o"],
+                                               L.ptr(t["rew"]), L.ptr(t["done"]), L.stream(v.device)))
+    return isolated_launch_ms(launch, v.device, n, sets, context=v_section(v) if in_step else None)
+
+
+def gather_p_ms(p, isolated=True, n=16, sets=4):
+    """The P-learner's obs gather (K_p batches per launch): isolated launch, or `n` launches back to back."""
+    ws = p._workspace(int(p.cfg.algo.batch_size))
+    K, B = ws["K"], ws["B"]
+    rows = K * B
+    idx = torch.randint(p.cur_capacity, size=(n, rows), device=p.device)
+    f = dict(dtype=torch.float32, device=p.device)
+    tiles = [dict(x_sa=torch.zeros((rows, ws["ld_sa"]), **f), x_obs=torch.zeros((rows, ws["ld_o"]), **f)) for _ in range(sets)]
+
+    def launch(i, s):
+        p._gather(ws, idx[i], rows, tiles[s]["x_sa"], tiles[s]["x_obs"])
+    if isolated:   # between two launches: a P step's forward + backward launches (scratch state: no optimiser step)
+        return isolated_launch_ms(launch, p.device, n, sets, context=lambda: p._step_kernels(ws, None, True, tiles=ws["slots"][0])), rows
+    with torch.cuda.device(p.device):
+        g = _graph_of(lambda: [launch(i, 0) for i in range(n)], p.device)
+        return _replay_ms(g) / n, rows
 
 
 def free_running(actor, v, p, env, cfg, device, n=160):
@@ -715,20 +828,36 @@ def main():
                 "frac": f_dom / (dms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS}
         # the replay gather as the schedule launches it: one launch for the next K V-steps (K = 1 in the per-step torch-RNG mode)
         K = int(v._workspace(args.batch)["K"])
-        gms = gather_ms(v, K)
+        gms_b2b = gather_ms(v, K)
+        gms = gather_isolated_ms(v, K)
         rec_ld = v.memory.ring.rec_ld
         per_batch = args.batch * ((2 * O + A) * 4 + 4 + 1 + 8 + (2 * O + A) * 4 + 4 + 4)   # 1557 B/sample @cfg2
         alg_bytes = K * per_batch
         line["roofline_gather"] = {"bound": "hbm", "kernel": "k_replay_gather_fused", "achieved": alg_bytes / (gms * 1e-3) / 1e9,
                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_bytes / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                   "method": "ONE launch at a time, the forward + backward launches of a V step between two gathers (as in the "
+                                             "schedule), 4 rotating output-tile sets; (graph of 16 x [V step, gather]) - (graph of 16 x [V step]), "
+                                             "HIP events, median of 5 interleaved replays",
+                                   "us_per_launch_behind_read_sweep": gather_isolated_ms(v, K, in_step=False) * 1e3,
                                    "traffic": traffic.get("gather_per_launch_bytes") if traffic.get("gather_batches_per_launch", 1) == K else None,
                                    "traffic_source": (f"committed profile {traffic_src}, NOT measured in this run") if traffic_src else None,
                                    "algorithmic_bytes": alg_bytes,
                                    "us_per_launch": gms * 1e3, "batches_per_launch": K, "rows_per_launch": K * args.batch,
-                                   "us_per_batch": gms * 1e3 / K, "record_bytes": rec_ld * 4}
+                                   "us_per_batch": gms * 1e3 / K, "record_bytes": rec_ld * 4,
+                                   "frac_back_to_back": alg_bytes / (gms_b2b * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                   "us_per_launch_back_to_back": gms_b2b * 1e3}
         if K > 1:   # the per-step launch (algo.rng=torch, injected draws) for comparison
-            g1 = gather_ms(v, 1)
+            g1 = gather_isolated_ms(v, 1)
             line["roofline_gather"]["single_batch_launch"] = {"us_per_launch": g1 * 1e3, "frac": per_batch / (g1 * 1e-3) / 1e9 / PEAK_HBM_GBS}
+        if mode == "schedule" and p.ready_to_learn():   # the P-learner's obs gather: read O floats + 8 B, write O floats per sample
+            pms, prows = gather_p_ms(p, True)
+            pms_b2b, _ = gather_p_ms(p, False)
+            p_alg = prows * (2 * O * 4 + 8)
+            line["roofline_gather_p"] = {"bound": "hbm", "kernel": "k_replay_gather_obs", "achieved": p_alg / (pms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
+                                         "unit": "GB/s", "frac": p_alg / (pms * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes": p_alg,
+                                         "us_per_launch": pms * 1e3, "rows_per_launch": prows, "method": "as roofline_gather, a P step's forward + backward launches between two gathers",
+                                         "frac_back_to_back": p_alg / (pms_b2b * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                         "us_per_launch_back_to_back": pms_b2b * 1e3}
         note("roofline sections measured")
         if world == 1 and mode == "schedule":
             line["free_running"] = free_running(actor, v, p, env, cfg, device)

@@ -445,13 +445,16 @@ class PLearnerRef:
 
 # =========================================================================== DDPG (BASELINE cfg #1)
 class DDPGRef:
-    """AgentDDPG.update_net inner iteration (pql/algo/ddpg.py:119-166) with no_tgt_actor=True:
-    shared batch, critic step (MSE TD), actor step (DPG), Polyak on the critic.
-    Normalisation here is the un-clamped RunningMeanStd.normalize (ddpg.py:124-126)."""
+    """AgentDDPG.update_net inner iteration (pql/algo/ddpg.py:119-166): shared batch, critic step (MSE TD), actor step (DPG),
+    Polyak on the critic and -- `actor_target` given, i.e. `no_tgt_actor=False` (ddpg.py:21-22,134-135) -- on the target actor,
+    which then supplies the target-policy actions (ddpg.py:70-79); without it the target actor IS the actor.
+    Normalisation here is the un-clamped RunningMeanStd.normalize (ddpg.py:124-126).
+    Pinned by tests/golden/ddpg.npz (the reference's own AgentDDPG, both settings)."""
 
-    def __init__(self, obs_dim, act_dim, hp: HyperRef, capacity, actor, q1, q2):
+    def __init__(self, obs_dim, act_dim, hp: HyperRef, capacity, actor, q1, q2, actor_target=None):
         self.hp = hp
         self.actor = [p.clone().requires_grad_(True) for p in actor]
+        self.actor_t = [p.detach().clone() for p in actor_target] if actor_target is not None else None
         self.q1 = [p.clone().requires_grad_(True) for p in q1]
         self.q2 = [p.clone().requires_grad_(True) for p in q2]
         self.t1 = [p.detach().clone() for p in self.q1]; self.t2 = [p.detach().clone() for p in self.q2]
@@ -466,7 +469,8 @@ class DDPGRef:
         if hp.obs_norm:
             obs = normalize_ref(obs, self.norm, clamp=False); nobs = normalize_ref(nobs, self.norm, clamp=False)
         with torch.no_grad():
-            na = target_noise_ref(actor_forward_ref(self.actor, nobs), draw, hp.tgt_pol_std, hp.tgt_pol_noise_bound)
+            tgt_actor = self.actor_t if self.actor_t is not None else self.actor
+            na = target_noise_ref(actor_forward_ref(tgt_actor, nobs), draw, hp.tgt_pol_std, hp.tgt_pol_noise_bound)
             tgt = rew + (1 - done) * (hp.gamma ** hp.nstep) * qmin_ref(self.t1, self.t2, nobs, na)
         c1, c2 = twin_forward_ref(self.q1, self.q2, obs, act)
         closs = F.mse_loss(c1, tgt) + F.mse_loss(c2, tgt)
@@ -476,6 +480,8 @@ class DDPGRef:
         aloss = -qmin_ref(frozen1, frozen2, obs, actor_forward_ref(self.actor, obs)).mean()
         self.aopt.apply(list(torch.autograd.grad(aloss, self.actor)), hp.max_grad_norm)
         polyak_ref([*self.t1, *self.t2], [p.detach() for p in cp], hp.tau)
+        if self.actor_t is not None:
+            polyak_ref(self.actor_t, [p.detach() for p in self.actor], hp.tau)
         return float(closs.detach()), float(aloss.detach())
 
 

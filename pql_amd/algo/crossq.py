@@ -5,13 +5,14 @@ clamp), `update_critic` (:144-157: ONE joint forward of [obs; next_obs] with [ac
 BatchNorm critic in training mode -- batch statistics over all 2B rows -- current Q from the first half, the target from the
 detached second half, twin MSE), `update_actor` (:159-166: DPG through the critic, which stays in training mode: its
 batch statistics are those of the B actor rows and the running statistics move again)}.  There is no target critic and,
-with `no_tgt_actor=True`, no target actor.  The critic is `pql_amd.models.batchnorm.DoubleQBatchNorm` (one-layer GEMM
+with `no_tgt_actor=True` (the default), no target actor either (`False`: a Polyak-averaged copy supplies the target-policy actions).  The critic is `pql_amd.models.batchnorm.DoubleQBatchNorm` (one-layer GEMM
 calls + the BatchNorm/ELU kernels of pql_amd/csrc/bn.hip); gather, actor, losses and the optimiser are the launches the
 DDPG baseline uses.  RNG order per update: replay indices, then the target-policy noise draw.
 """
 from __future__ import annotations
 
 import ctypes as C
+from copy import deepcopy
 
 import numpy as np
 import torch
@@ -40,9 +41,8 @@ class AgentCrossQ(PQLActor):
             self.critic = cri_class(self.obs_dim, self.action_dim, hidden_layers=hidden).to(self.device)
         if not hasattr(self.critic, "backward_raw"):
             raise ValueError("CrossQ needs the BatchNorm critic (cri_class: DoubleQBatchNorm)")
-        if not algo.no_tgt_actor:
-            raise NotImplementedError("separate target actor (no_tgt_actor=False) is not used by any shipped config")
-        self.actor_target = self.actor
+        # crossQ.py:21,71,132-133: the target-policy actions come from a Polyak-averaged copy unless no_tgt_actor=True (the default)
+        self.actor_target = self.actor if algo.no_tgt_actor else deepcopy(self.actor)
         self.aopt, self.copt = _AdamState(self.actor.arena.data), _AdamState(self.critic.arena.data)
         self.closs = torch.zeros(LOSS_RING, device=self.device)
         self.aloss = torch.zeros(LOSS_RING, device=self.device)
@@ -94,7 +94,7 @@ class AgentCrossQ(PQLActor):
             ws["x_obs"][:, :O].copy_(ws["x_sa"][:, :O])
             ws["x_pi"][:, :O].copy_(ws["x_sa"][:, :O])
             # ---- critic step (crossQ.py:144-157)
-            mlp_forward_raw(al, self.actor.arena.data, ws["xn_obs"], L.ACT_TANH_NOISE, draw, algo.noise.tgt_pol_std,
+            mlp_forward_raw(al, self.actor_target.arena.data, ws["xn_obs"], L.ACT_TANH_NOISE, draw, algo.noise.tgt_pol_std,
                             algo.noise.tgt_pol_noise_bound, ws["acts_a"], ws["xn_sa"][:, O:])
             q_all = self.critic.forward_raw(ws["x_all"], training=True)          # (2, 2B, 32): batch statistics over all 2B rows
             ws["q"].copy_(q_all[:, :B]); ws["qt"].copy_(q_all[:, B:])            # current / (detached) next halves
@@ -116,6 +116,9 @@ class AgentCrossQ(PQLActor):
                                             L.ptr(ws["acts_a"]), L.ptr(ws["dz_a"]), L.ptr(ws["ga"]), ws["splits"], None, 0, 0, 0, None, 0,
                                             L.ptr(ws["bwd_a"]), ws["bwd_a"].numel(), st))
             apply_optimizer(self.actor.arena.data, ws["ga"], self.aopt, None, algo.actor_lr, algo.max_grad_norm, 0.0, 1.0, dev)
+            if self.actor_target is not self.actor:   # crossQ.py:132-133
+                L.check(L.lib.pqlk_polyak(L.ptr(self.actor_target.arena.data), L.ptr(self.actor.arena.data),
+                                          self.actor.arena.numel(), float(algo.tau), st))
 
     def update_net(self, memory):
         n = int(self.cfg.algo.update_times)

@@ -1,8 +1,8 @@
 """Synchronous DDPG on the same kernels (BASELINE config #1 plumbing).
 
 Mirrors the hot part of `pql/algo/ddpg.py`: `AgentDDPG.update_net(memory)` = `update_times` x {sample,
-obs_rms.normalize (NO clamp, ddpg.py:124-126), critic step (:147-157), actor step (:159-166), Polyak}, with
-`no_tgt_actor=True` (the target actor IS the actor, ddpg.py:22).  It is the V- and P-learner launch sequences
+obs_rms.normalize (NO clamp, ddpg.py:124-126), critic step (:147-157), actor step (:159-166), Polyak of the critic target and,
+with `no_tgt_actor=False`, of the target actor (:134-135; `no_tgt_actor=True`, the shipped default: the target actor IS the actor, :22).  It is the V- and P-learner launch sequences
 run back to back on one shared replay sample; the ActorCriticBase plumbing of the fork (bidex, success
 trackers) is out of scope.
 """
@@ -37,9 +37,8 @@ class AgentDDPG(PQLActor):
             self.actor = act_class(self.obs_dim, self.action_dim, hidden_layers=hidden).to(self.device)
             self.critic = cri_class(self.obs_dim, self.action_dim, hidden_layers=hidden).to(self.device)
         self.critic_target = deepcopy(self.critic)
-        if not algo.no_tgt_actor:
-            raise NotImplementedError("separate target actor (no_tgt_actor=False) is not used by any shipped config")
-        self.actor_target = self.actor
+        # ddpg.py:21-22: a Polyak-averaged copy of the actor, or (no_tgt_actor=True, every shipped config) the actor itself
+        self.actor_target = self.actor if algo.no_tgt_actor else deepcopy(self.actor)
         self.aopt, self.copt = _AdamState(self.actor.arena.data), _AdamState(self.critic.arena.data)
         self.closs = torch.zeros(LOSS_RING, device=self.device)
         self.aloss = torch.zeros(LOSS_RING, device=self.device)
@@ -94,7 +93,7 @@ class AgentDDPG(PQLActor):
             ws["x_obs"][:, :O].copy_(ws["x_sa"][:, :O])
             ws["x_pi"][:, :O].copy_(ws["x_sa"][:, :O])
             # ---- critic step (ddpg.py:147-157)
-            mlp_forward_raw(al, self.actor.arena.data, ws["xn_obs"], L.ACT_TANH_NOISE, draw, algo.noise.tgt_pol_std,
+            mlp_forward_raw(al, self.actor_target.arena.data, ws["xn_obs"], L.ACT_TANH_NOISE, draw, algo.noise.tgt_pol_std,
                             algo.noise.tgt_pol_noise_bound, ws["acts_a"], ws["xn_sa"][:, O:])
             mlp_forward_raw(cl, self.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"])
             mlp_forward_raw(cl, self.critic.arena.data, ws["x_sa"], L.ACT_NONE, acts=ws["acts_c"])
@@ -122,6 +121,9 @@ class AgentDDPG(PQLActor):
             # ---- soft_update(critic_target, critic, tau)
             L.check(L.lib.pqlk_polyak(L.ptr(self.critic_target.arena.data), L.ptr(self.critic.arena.data),
                                       self.critic.arena.numel(), float(algo.tau), st))
+            if self.actor_target is not self.actor:   # ddpg.py:134-135
+                L.check(L.lib.pqlk_polyak(L.ptr(self.actor_target.arena.data), L.ptr(self.actor.arena.data),
+                                          self.actor.arena.numel(), float(algo.tau), st))
 
     def update_net(self, memory):
         n = int(self.cfg.algo.update_times)

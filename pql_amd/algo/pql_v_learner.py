@@ -35,7 +35,8 @@ from pql_amd.utils.common import Tracker, load_class_from_path
 
 LOSS_RING = 5  # Tracker(5) of the reference (:54)
 # gather: +-5 clamp (bit 0); the learners' input tiles are allocated zeroed and nothing else writes their pad columns (bit 1)
-GATHER_FLAGS = 1 | 2
+# (PQL_GATHER_FLAGS: A/B switch for the launch-shape / cache-policy bits of include/pqlk.h, tools/ab_bench.sh)
+GATHER_FLAGS = int(os.environ.get("PQL_GATHER_FLAGS", 1 | 2))
 
 
 def _cfg_get(node, name, default=None):

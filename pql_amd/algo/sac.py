@@ -3,7 +3,7 @@
 Mirrors the hot part of `pql/algo/sac.py`: `AgentSAC.update_net(memory)` = `update_times` x {sample, `obs_rms.normalize`
 (no clamp), `update_critic` (:138-146: entropy-regularised n-step target through the squashed-Gaussian policy, twin MSE),
 `update_actor` (:148-161: mean(alpha log pi - min Q) through the UPDATED critic, then the temperature step on
-`log_alpha`), Polyak on the critic}, with `no_tgt_actor=True`.  Everything the DDPG baseline already runs (gather,
+`log_alpha`), Polyak on the critic (and on the otherwise unused target policy when `no_tgt_actor=False`)}.  Everything the DDPG baseline already runs (gather,
 fp32-MFMA MLP forward/backward, TD loss, clip+AdamW, Polyak) is reused; the new math is four small launches
 (`pql_amd/csrc/sac.hip`): the policy head forward / backward and the two temperature kernels.  `log_alpha` lives on the
 device and is read there by the kernels that need alpha, so an update has no host round trip and is graph-capturable.
@@ -44,9 +44,9 @@ class AgentSAC(PQLActor):
         if self.actor.layout.dims[-1] != 2 * self.action_dim:
             raise ValueError("SAC needs a policy with a [mu | log_std] head (act_class: TanhDiagGaussianMLPPolicy)")
         self.critic_target = deepcopy(self.critic)
-        if not algo.no_tgt_actor:
-            raise NotImplementedError("separate target actor (no_tgt_actor=False) is not used by any shipped config")
-        self.actor_target = self.actor
+        # sac.py:19,104-105: with no_tgt_actor=False the reference keeps a Polyak-averaged copy of the policy; its critic target
+        # (sac.py:138-146) samples the next action from `self.actor` either way, so the copy is state only (checkpoints)
+        self.actor_target = self.actor if algo.no_tgt_actor else deepcopy(self.actor)
         self.aopt, self.copt = _AdamState(self.actor.arena.data), _AdamState(self.critic.arena.data)
         # temperature (sac.py:22-26,32-42): learned log_alpha starting at 0, or a fixed alpha from the config
         self.learn_alpha = algo.alpha is None
@@ -159,6 +159,9 @@ class AgentSAC(PQLActor):
             # ---- soft_update(critic_target, critic, tau)
             L.check(L.lib.pqlk_polyak(L.ptr(self.critic_target.arena.data), L.ptr(self.critic.arena.data),
                                       self.critic.arena.numel(), float(algo.tau), st))
+            if self.actor_target is not self.actor:   # sac.py:104-105
+                L.check(L.lib.pqlk_polyak(L.ptr(self.actor_target.arena.data), L.ptr(self.actor.arena.data),
+                                          self.actor.arena.numel(), float(algo.tau), st))
 
     def update_net(self, memory):
         n = int(self.cfg.algo.update_times)

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
       int64_t src = srcs[i];
       if (src < 0 || src >= capacity) src = 0;
       if (cl < nchunk) {
-        if (nt_loads) {   // records are read once per sample: keep them out of the caches the output tiles will be read from
+        if (nt_loads & 1) {   // records are read once per sample: keep them out of the caches the output tiles will be read from
           const f4n t = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(records + src * L.ld) + cl);
           v[i] = make_float4(t[0], t[1], t[2], t[3]);
         } else {
@@ -352,8 +352,10 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
       }
       const float e[4] = {x.x, x.y, x.z, x.w};
       if (dstA) {
-        if (vecA) *reinterpret_cast<float4*>(dstA + r * ldA) = x;
-        else {
+        if (vecA) {
+          if (nt_loads & 2) __builtin_nontemporal_store(f4n{x.x, x.y, x.z, x.w}, reinterpret_cast<f4n*>(dstA + r * ldA));
+          else *reinterpret_cast<float4*>(dstA + r * ldA) = x;
+        } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (j < nvalid) dstA[r * ldA + j] = e[j];
@@ -390,6 +392,92 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
   }
 }
 
+// Fast path for OBS-ONLY rings (the P-learner's replay, pql_p_learner.py:32-37,49-50).  A record is O floats -- 384 B at cfg #2,
+// 22 of a wave's 64 lanes at one 16-B chunk per lane -- so with one record per wave instruction (the generic kernel above, which
+// also re-decodes the field per row: 18 us per 32 768 rows, 0.16 of the HBM roof) two thirds of every load and store instruction
+// are idle lanes.  Here a record takes P = 2^lgp lanes (the power of two >= its chunk count) and G = 64 / P records share each
+// instruction; a lane's chunk, destinations and normalisation constants are fixed for the whole kernel (as in
+// k_replay_gather_fast), a wave keeps R x G records in flight, and the sample indices run one trip ahead of the records.
+template <bool HAS_NORM, int R>
+__global__ __launch_bounds__(256) void k_replay_gather_obs(const float* __restrict__ records, RecLayout L, int64_t capacity,
+                                                           const int64_t* __restrict__ idx, int64_t b,
+                                                           const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                                                           int clamp5, float* __restrict__ x_sa, int64_t ld_sa,
+                                                           float* __restrict__ x_obs, int64_t ld_o, int write_pads, int lgp) {
+  const int lane = threadIdx.x & 63;
+  const int P = 1 << lgp, G = 64 >> lgp;
+  const int grp = lane >> lgp, cl = lane & (P - 1);   // record of the instruction, chunk of the record
+  const int c = cl << 2;
+  const int nchunk = L.used >> 2;
+  const bool active = cl < nchunk;
+  const int nvalid = active ? min(4, L.O - c) : 0;   // < 4 only in the last chunk when O is not a multiple of 4
+  float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (HAS_NORM && active) {
+    float mm[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < nvalid) { mm[j] = mean[c + j]; ss[j] = sqrtf(var[c + j] + eps); }
+    m4 = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    s4 = make_float4(ss[0], ss[1], ss[2], ss[3]);
+  }
+  const int64_t rows_trip = (int64_t)R * G;
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * 4;
+  int64_t nsrc[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int64_t r = wave * rows_trip + i * G + grp;
+    nsrc[i] = r < b ? idx[r] : 0;
+  }
+  for (int64_t r0 = wave * rows_trip; r0 < b; r0 += nwaves * rows_trip) {
+    float4 v[R];
+    int64_t srcs[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) srcs[i] = nsrc[i];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int64_t rn = r0 + nwaves * rows_trip + i * G + grp;
+      nsrc[i] = rn < b ? idx[rn] : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      int64_t src = srcs[i];
+      if (src < 0 || src >= capacity) src = 0;   // never fault on a bad index
+      v[i] = active ? reinterpret_cast<const float4*>(records + src * L.ld)[cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const int64_t r = r0 + i * G + grp;
+      if (r >= b) continue;
+      float4 x = v[i];
+      if (HAS_NORM) {
+        x.x = (x.x - m4.x) / s4.x; x.y = (x.y - m4.y) / s4.y; x.z = (x.z - m4.z) / s4.z; x.w = (x.w - m4.w) / s4.w;
+        if (clamp5) {
+          x.x = fminf(fmaxf(x.x, -5.f), 5.f); x.y = fminf(fmaxf(x.y, -5.f), 5.f);
+          x.z = fminf(fmaxf(x.z, -5.f), 5.f); x.w = fminf(fmaxf(x.w, -5.f), 5.f);
+        }
+      }
+      if (nvalid == 4) {
+        if (x_sa) *reinterpret_cast<float4*>(x_sa + r * ld_sa + c) = x;
+        if (x_obs) *reinterpret_cast<float4*>(x_obs + r * ld_o + c) = x;
+      } else {
+        const float e[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < nvalid) {
+            if (x_sa) x_sa[r * ld_sa + c + j] = e[j];
+            if (x_obs) x_obs[r * ld_o + c + j] = e[j];
+          }
+      }
+      if (!write_pads) continue;   // (the learners keep the pads zero themselves: PQLK_GATHER_PADS_ZERO)
+      if (x_sa)
+        for (int64_t k = L.O + cl; k < ld_sa; k += P) x_sa[r * ld_sa + k] = 0.f;
+      if (x_obs)
+        for (int64_t k = L.O + cl; k < ld_o; k += P) x_obs[r * ld_o + k] = 0.f;
+    }
+  }
+}
+
 template <bool HAS_NORM>
 static void launch_gather_fused(int nchunk, unsigned blocks, hipStream_t st, const float* records, RecLayout L, int64_t capacity,
                                 const int64_t* idx, int64_t b, const float* mean, const float* var, float eps, int clamp5,
@@ -411,7 +499,7 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
                                         pqlk_stream_t stream) {
   const int clamp5 = flags & PQLK_GATHER_CLAMP5;
   const int write_pads = (flags & PQLK_GATHER_PADS_ZERO) ? 0 : 1;
-  const int tune_R = (flags >> 8) & 15, tune_wpc = (flags >> 12) & 63, nt_loads = (flags & PQLK_GATHER_NT_LOADS) ? 1 : 0;
+  const int tune_R = (flags >> 8) & 15, tune_wpc = (flags >> 12) & 63, nt_loads = ((flags & PQLK_GATHER_NT_LOADS) ? 1 : 0) | ((flags & PQLK_GATHER_NT_STORES) ? 2 : 0);
   PQLK_REQUIRE(ring && ring->records && idx, PQLK_E_NULL);
   PQLK_REQUIRE(ring->obs_dim > 0 && ring->capacity > 0 && b >= 0, PQLK_E_SHAPE);
   RecLayout L = rec_layout(ring->obs_dim, ring->act_dim);
@@ -466,6 +554,31 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
     if (mean) PQLK_GATHER_FAST_R(true); else PQLK_GATHER_FAST_R(false);
 #undef PQLK_GATHER_FAST_R
 #undef PQLK_GATHER_FAST
+    PQLK_LAUNCH_CHECK();
+    return PQLK_OK;
+  }
+  // obs-only ring whose record fits one 16-B chunk per lane (O <= 256): several records per wave instruction
+  if (L.A < 0 && nchunk <= 64 && pqlk_aligned16(x_sa) && pqlk_aligned16(xn_obs) && (x_sa || xn_obs)) {
+    int lgp = 0;
+    while ((1 << lgp) < nchunk) ++lgp;
+    const int G = 64 >> lgp;
+    // rows in flight per wave: R x G, R chosen so that the launch still has ~16 waves per CU to issue from (32 768 rows of
+    // cfg #2, G = 2: R = 4, 4096 waves, one trip); waves per CU capped at 16 (grid-stride trips beyond)
+    const int64_t groups = (b + G - 1) / G;
+    int R = groups >= 4 * 4096 ? 4 : (groups >= 2 * 4096 ? 2 : 1);
+    if (tune_R == 1 || tune_R == 2 || tune_R == 4) R = tune_R;
+    const int wpc = tune_wpc ? tune_wpc : 16;
+    int64_t fb = (groups + 4 * R - 1) / (4 * R);
+    if (fb > 256 * (int64_t)wpc / 4) fb = 256 * (int64_t)wpc / 4;
+    const dim3 g((unsigned)fb), t(256);
+#define PQLK_GATHER_OBS(NORM, RR) \
+    hipLaunchKernelGGL((k_replay_gather_obs<NORM, RR>), g, t, 0, pqlk_s(stream), ring->records, L, ring->capacity, idx, b, mean, var, eps, \
+                       clamp5, x_sa, ld_sa, xn_obs, ld_o, write_pads, lgp)
+#define PQLK_GATHER_OBS_R(NORM) \
+    do { if (R == 1) PQLK_GATHER_OBS(NORM, 1); else if (R == 2) PQLK_GATHER_OBS(NORM, 2); else PQLK_GATHER_OBS(NORM, 4); } while (0)
+    if (mean) PQLK_GATHER_OBS_R(true); else PQLK_GATHER_OBS_R(false);
+#undef PQLK_GATHER_OBS_R
+#undef PQLK_GATHER_OBS
     PQLK_LAUNCH_CHECK();
     return PQLK_OK;
   }

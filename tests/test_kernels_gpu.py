@@ -151,6 +151,39 @@ def test_obs_ring_gather(dev, ref):
     assert torch.equal(x_sa[:, :O].cpu(), oracle.gather(idx)) and torch.all(x_sa[:, O:] == 0)
 
 
+@pytest.mark.parametrize("O,B", [(88, 8192 + 5), (88, 4 * 8192), (8, 777), (63, 1001), (211, 2049), (256, 515), (260, 300)])
+def test_obs_ring_gather_shapes_vs_oracle(dev, ref, O, B):
+    """The obs-only ring's gather (several records per wave instruction up to O = 256, the generic kernel beyond) against the
+    oracle's `memory[idx]` + normalize (pql_p_learner.py:49-52, common.py:139-145): bit-exact, pads zeroed or left alone as the
+    flag word says, whatever launch shape the row count selects (one trip, several, a ragged last one)."""
+    from pql_amd import _lib as L
+    from pql_amd.replay.simple_replay import RecordRing
+    cap = 5000
+    ring = RecordRing(cap, O, -1, dev)
+    mem = T(dd.uniform((cap, O), 70 + O, -3, 3))
+    ring.insert_segments([(0, 0, cap)], mem.to(dev))
+    idx = T(dd.integers((B,), 9 + O, cap))
+    mean, var = T(dd.uniform((O,), 6, -0.5, 0.5)), T(dd.uniform((O,), 7, 0.5, 2.0))
+    want_raw = mem[idx]
+    want_norm = ref.normalize_ref(want_raw, (mean, var, 1e-4))
+    idx_d, mean_d, var_d = idx.to(dev), mean.to(dev), var.to(dev)
+    for norm in (False, True):
+        for flags in (1, 1 | 2, 1 | 2 | (2 << 8) | (8 << 12), 1 | (4 << 8) | (4 << 12)):   # pads written / left; forced launch shapes
+            x_sa = torch.full((B, L.ld(O + 5)), 7.0, device=dev); x_o = torch.full((B, L.ld(O)), 7.0, device=dev)
+            L.check(L.lib.pqlk_replay_gather_fused(C.byref(ring.desc), L.ptr(idx_d), B, L.ptr(mean_d) if norm else None,
+                                                   L.ptr(var_d) if norm else None, 1e-4, flags, L.ptr(x_sa), x_sa.stride(0), None,
+                                                   L.ptr(x_o), x_o.stride(0), None, None, L.stream(dev)))
+            want = want_norm if norm else want_raw
+            pad = 7.0 if flags & 2 else 0.0
+            assert torch.equal(x_o[:, :O].cpu(), want) and torch.all(x_o[:, O:] == pad), (norm, flags)
+            assert torch.equal(x_sa[:, :O].cpu(), want) and torch.all(x_sa[:, O:] == pad), (norm, flags)
+    # one destination only
+    x_o = torch.zeros((B, L.ld(O)), device=dev)
+    L.check(L.lib.pqlk_replay_gather_fused(C.byref(ring.desc), L.ptr(idx_d), B, None, None, 0.0, 3, None, 0, None, L.ptr(x_o), x_o.stride(0),
+                                           None, None, L.stream(dev)))
+    assert torch.equal(x_o[:, :O].cpu(), want_raw)
+
+
 # --------------------------------------------------------------------------- n-step
 @pytest.mark.parametrize("name", ["kat3", "n3", "n5", "n1"])
 def test_nstep_golden(golden, dev, name):

@@ -533,6 +533,70 @@ def test_ddpg_update_vs_oracle(dev):
     np.testing.assert_allclose(lay.weight(agent.critic_target.arena.data, 1, 1).cpu().numpy(), orc.t2[2].numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("tag", ["tgt0", "tgt1"])
+def test_ddpg_golden_trace(golden, dev, tag):
+    """AgentDDPG.update_once (HIP launch sequence) vs three iterations of the reference's own AgentDDPG.update_critic / update_actor /
+    soft_update (tests/golden/ddpg.npz, pql/algo/ddpg.py:119-166) on identical samples and target-policy noise: losses, every
+    parameter tensor of the actor, the critic and the targets.  tgt0: no_tgt_actor=True (every shipped config); tgt1:
+    no_tgt_actor=False -- a Polyak-averaged target actor that starts away from the actor (ddpg.py:21-22,134-135)."""
+    from pql_amd.algo.ddpg import AgentDDPG
+    from pql_amd.envs.synthetic import create_task_env
+    from pql_amd.replay.simple_replay import ReplayBuffer
+    g = golden("ddpg"); O, A = 8, 2
+    cfg = _ddpg_cfg(["algo.batch_size=64", "algo.memory_size=400", f"algo.no_tgt_actor={tag == 'tgt0'}"])
+    agent = AgentDDPG(create_task_env(cfg), cfg)
+    agent.actor.load_state_dict(_sd(dd.mlp_state(O, A, 11)))
+    agent.critic.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 21))); agent.critic_target.arena.data.copy_(agent.critic.arena.data)
+    assert (agent.actor_target is agent.actor) == (tag == "tgt0")
+    if tag == "tgt1":
+        agent.actor_target.load_state_dict(_sd(dd.mlp_state(O, A, 13)))
+    agent.obs_rms.mean, agent.obs_rms.var = T(g["ddpg_norm_mean"]).to(dev), T(g["ddpg_norm_var"]).to(dev)
+    memory = ReplayBuffer(400, (O,), A, device=dev)
+    memory.add_to_buffer(tuple(t.to(dev) for t in _fill(O, A, 300, 810)))
+    for s in range(3):
+        agent.update_once(memory, indices=T(g[f"ddpg_{tag}_idx"][s]), noise=T(g[f"ddpg_{tag}_noise"][s]))
+        np.testing.assert_allclose(agent.closs[s % 5].item(), g[f"ddpg_{tag}_closs"][s], rtol=2e-5)
+        np.testing.assert_allclose(agent.aloss[s % 5].item(), g[f"ddpg_{tag}_aloss"][s], rtol=2e-5)
+        _check_module(agent.actor, g, f"ddpg_{tag}_s{s}_a_")
+        _check_module(agent.critic, g, f"ddpg_{tag}_s{s}_c_")
+        _check_module(agent.critic_target, g, f"ddpg_{tag}_s{s}_t_")
+        if tag == "tgt1":
+            _check_module(agent.actor_target, g, f"ddpg_{tag}_s{s}_at_")
+    np.testing.assert_allclose(agent.actor.layout.weight(agent.actor.arena.data, 0, 3).cpu().numpy(), g[f"ddpg_{tag}_final_actor_last_w"],
+                               rtol=5e-5, atol=5e-7)
+    np.testing.assert_allclose(agent.critic_target.layout.weight(agent.critic_target.arena.data, 0, 3).cpu().numpy(),
+                               g[f"ddpg_{tag}_final_tq1_last_w"], rtol=5e-5, atol=5e-7)
+    if tag == "tgt1":
+        np.testing.assert_allclose(agent.actor_target.layout.weight(agent.actor_target.arena.data, 0, 3).cpu().numpy(),
+                                   g[f"ddpg_{tag}_final_tactor_last_w"], rtol=5e-5, atol=5e-7)
+
+
+@pytest.mark.parametrize("algo", ["sac", "crossq"])
+def test_target_actor_is_polyak_averaged_in_sac_and_crossq(dev, algo):
+    """no_tgt_actor=False (sac.py:19,104-105; crossQ.py:21,132-133): the target policy is a separate arena that follows the policy by
+    theta' <- tau theta + (1 - tau) theta' after every update; CrossQ takes its target-policy actions from it."""
+    from pql_amd.envs.synthetic import create_task_env
+    from pql_amd.replay.simple_replay import ReplayBuffer
+    if algo == "sac":
+        from pql_amd.algo.sac import AgentSAC as Agent
+        cfg = _sac_cfg(["algo.no_tgt_actor=False"])
+    else:
+        from pql_amd.algo.crossq import AgentCrossQ as Agent
+        cfg = _crossq_cfg(["algo.no_tgt_actor=False"])
+    agent = Agent(create_task_env(cfg), cfg)
+    assert agent.actor_target is not agent.actor and torch.equal(agent.actor_target.arena.data, agent.actor.arena.data)
+    O, A = 8, 2
+    memory = ReplayBuffer(400, (O,), A, device=dev)
+    memory.add_to_buffer(tuple(t.to(dev) for t in _fill(O, A, 300, 810)))
+    tau = float(cfg.algo.tau)
+    for _ in range(2):
+        before = agent.actor_target.arena.data.clone()
+        agent.update_once(memory)
+        want = agent.actor.arena.data * tau + before * (1.0 - tau)     # soft_update, torch_util.py:9-12
+        torch.testing.assert_close(agent.actor_target.arena.data, want, rtol=0, atol=0)
+    assert not torch.equal(agent.actor_target.arena.data, agent.actor.arena.data)
+
+
 def test_train_baselines_entry_point_cfg1(dev):
     import importlib.util, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

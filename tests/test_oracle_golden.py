@@ -317,6 +317,36 @@ def test_sac_trace(golden):
     np.testing.assert_allclose(s.q1[-2].detach().numpy(), g["sac_final_q1_last_w"], rtol=5e-5, atol=5e-7)
 
 
+@pytest.mark.parametrize("tag", ["tgt0", "tgt1"])
+def test_ddpg_trace(golden, tag):
+    """DDPGRef (row a26) vs three iterations of the reference's own AgentDDPG.update_critic / update_actor / soft_update
+    (pql/algo/ddpg.py:119-166): tgt0 = no_tgt_actor=True (the shipped configs), tgt1 = a Polyak-averaged target actor that starts
+    away from the actor."""
+    g = golden("ddpg"); O, A = 8, 2
+    st = dd.doubleq_state(O, A, 1, 21)
+    tgt = ref.params_from_state(dd.mlp_state(O, A, 13)) if tag == "tgt1" else None
+    s = ref.DDPGRef(O, A, ref.HyperRef(batch_size=64), 400, ref.params_from_state(dd.mlp_state(O, A, 11)),
+                    ref.params_from_state(st, "net_q1.net."), ref.params_from_state(st, "net_q2.net."), actor_target=tgt)
+    s.ring.insert(*_fill(O, A, 300, 810))
+    s.norm = (T(g["ddpg_norm_mean"]), T(g["ddpg_norm_var"]), 1e-4)
+    cn = _named(["net_q1.net.", "net_q2.net."], [s.q1, s.q2]); an = _named(["net."], [s.actor])
+    for i in range(3):
+        cl, al = s.update_once(T(g[f"ddpg_{tag}_idx"][i]), T(g[f"ddpg_{tag}_noise"][i]))
+        np.testing.assert_allclose(cl, g[f"ddpg_{tag}_closs"][i], rtol=2e-5)
+        np.testing.assert_allclose(al, g[f"ddpg_{tag}_aloss"][i], rtol=2e-5)
+        _check_params(zip(an, s.actor), g, f"ddpg_{tag}_s{i}_a_")
+        _check_params(zip(cn, [*s.q1, *s.q2]), g, f"ddpg_{tag}_s{i}_c_")
+        _check_params(zip(cn, [*s.t1, *s.t2]), g, f"ddpg_{tag}_s{i}_t_")
+        if tag == "tgt1":
+            _check_params(zip(an, s.actor_t), g, f"ddpg_{tag}_s{i}_at_")
+    np.testing.assert_allclose(s.actor[-2].detach().numpy(), g[f"ddpg_{tag}_final_actor_last_w"], rtol=5e-5, atol=5e-7)
+    np.testing.assert_allclose(s.q1[-2].detach().numpy(), g[f"ddpg_{tag}_final_q1_last_w"], rtol=5e-5, atol=5e-7)
+    np.testing.assert_allclose(s.t1[-2].detach().numpy(), g[f"ddpg_{tag}_final_tq1_last_w"], rtol=5e-5, atol=5e-7)
+    if tag == "tgt1":
+        np.testing.assert_allclose(s.actor_t[-2].numpy(), g[f"ddpg_{tag}_final_tactor_last_w"], rtol=5e-5, atol=5e-7)
+        assert not np.allclose(g["ddpg_tgt1_closs"], g["ddpg_tgt0_closs"])   # the two settings really differ
+
+
 # --------------------------------------------------------------------------- CrossQ (SURVEY 8f rank 4)
 def _bn_lists(state, hidden=(512, 256, 128)):
     lin, bn = [], []

@@ -84,6 +84,7 @@ def _import_reference():
     from pql.algo.sac import AgentSAC
     from pql.models.mlp import DoubleQBatchNorm
     from pql.algo.crossQ import AgentCrossQ
+    from pql.algo.ddpg import AgentDDPG
     return NS(**locals())
 
 
@@ -560,6 +561,61 @@ def gen_crossq(R, out, steps=3):
     out["cq_norm_mean"] = norm[0]; out["cq_norm_var"] = norm[1]
 
 
+# --------------------------------------------------------------------------- DDPG (BASELINE cfg #1)
+def gen_ddpg(R, out, steps=3):
+    """AgentDDPG.update_net's inner iteration (pql/algo/ddpg.py:119-166) on the reference itself: shared batch, obs_rms.normalize
+    (no clamp), update_critic, update_actor, soft_update of the critic target and -- `no_tgt_actor=False` -- of the actor target.
+    Built with __new__ + attributes like the SAC / CrossQ traces (its __post_init__ wants an env); draws captured.  Two traces:
+    `tgt0` (no_tgt_actor=True: the target actor IS the actor, ddpg.py:22) and `tgt1` (a Polyak-averaged copy, ddpg.py:134-135)."""
+    O, A, B = 8, 2, 64
+    norm = (dd.uniform((O,), 801, -0.5, 0.5), dd.uniform((O,), 802, 0.5, 2.0))
+    data = [T(d) for d in _fill_data(O, A, 300, 810)]
+    for tag, no_tgt in (("tgt0", True), ("tgt1", False)):
+        cfg = NS(info_track_keys=None, device="cpu",
+                 algo=NS(batch_size=B, obs_norm=True, gamma=0.99, nstep=3, tau=0.05, max_grad_norm=0.5, no_tgt_actor=no_tgt, update_times=1,
+                         noise=NS(tgt_pol_std=0.8, tgt_pol_noise_bound=0.2)))
+        s = R.AgentDDPG.__new__(R.AgentDDPG)
+        s.cfg, s.obs_dim, s.action_dim, s.device = cfg, (O,), A, torch.device("cpu")
+        s.actor = R.TanhMLPPolicy((O,), A); load_state(s.actor, dd.mlp_state(O, A, 11))
+        s.critic = R.DoubleQ((O,), A); load_state(s.critic, dd.doubleq_state(O, A, 1, 21))
+        s.critic_target = deepcopy(s.critic)
+        s.actor_target = s.actor if no_tgt else deepcopy(s.actor)     # ddpg.py:21-22
+        if not no_tgt:   # start the target actor AWAY from the actor, so that a build that reads the wrong one cannot pass
+            load_state(s.actor_target, dd.mlp_state(O, A, 13))
+        s.actor_optimizer = torch.optim.AdamW(s.actor.parameters(), 5e-4)
+        s.critic_optimizer = torch.optim.AdamW(s.critic.parameters(), 5e-4)
+        s.obs_rms = R.RunningMeanStd(shape=(O,), device="cpu"); s.obs_rms.mean, s.obs_rms.var = T(norm[0]), T(norm[1])
+        closs, aloss, idxs = [], [], []
+        with _Capture(9100) as cap:     # torch.normal of add_normal_noise (get_tgt_policy_actions, ddpg.py:70-79)
+            for st in range(steps):
+                idx = T(dd.integers((B,), 9200 + st, 300)); idxs.append(idx.numpy())
+                obs, act, rew, nobs, done = (d[idx] for d in data)
+                obs, nobs = s.obs_rms.normalize(obs), s.obs_rms.normalize(nobs)
+                cl, _ = s.update_critic(obs, act, rew, nobs, done)
+                al, _ = s.update_actor(obs)
+                R.soft_update(s.critic_target, s.critic, cfg.algo.tau)
+                if not cfg.algo.no_tgt_actor:
+                    R.soft_update(s.actor_target, s.actor, cfg.algo.tau)
+                closs.append(cl); aloss.append(al)
+                for k, p in s.actor.named_parameters():
+                    out[f"ddpg_{tag}_s{st}_a_{k}"] = dd.summarize(p.detach().numpy())
+                for k, p in s.critic.named_parameters():
+                    out[f"ddpg_{tag}_s{st}_c_{k}"] = dd.summarize(p.detach().numpy())
+                for k, p in s.critic_target.named_parameters():
+                    out[f"ddpg_{tag}_s{st}_t_{k}"] = dd.summarize(p.detach().numpy())
+                if not no_tgt:
+                    for k, p in s.actor_target.named_parameters():
+                        out[f"ddpg_{tag}_s{st}_at_{k}"] = dd.summarize(p.detach().numpy())
+        out[f"ddpg_{tag}_closs"] = np.array(closs, np.float64); out[f"ddpg_{tag}_aloss"] = np.array(aloss, np.float64)
+        out[f"ddpg_{tag}_idx"] = np.stack(idxs); out[f"ddpg_{tag}_noise"] = np.stack(cap.noise)
+        out[f"ddpg_{tag}_final_actor_last_w"] = s.actor.state_dict()["net.6.weight"].numpy().copy()
+        out[f"ddpg_{tag}_final_q1_last_w"] = s.critic.state_dict()["net_q1.net.6.weight"].numpy().copy()
+        out[f"ddpg_{tag}_final_tq1_last_w"] = s.critic_target.state_dict()["net_q1.net.6.weight"].numpy().copy()
+        if not no_tgt:
+            out[f"ddpg_{tag}_final_tactor_last_w"] = s.actor_target.state_dict()["net.6.weight"].numpy().copy()
+    out["ddpg_norm_mean"] = norm[0]; out["ddpg_norm_var"] = norm[1]
+
+
 def gen_ckpt(R, out):
     """f1: the ONE weight file the reference ships (pql/model.pth, a PPO actor / critic pair in the checkpoint format of
     pql/utils/model_util.py:24-36) read with weights_only=True and pushed through the reference's MLPNet (mlp.py:27-40):
@@ -592,7 +648,7 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
     for name, fn in (("replay", gen_ring), ("nstep", gen_nstep), ("models", gen_models), ("math", gen_math),
-                     ("learners", gen_learners), ("sac", gen_sac), ("crossq", gen_crossq), ("ckpt", gen_ckpt)):
+                     ("learners", gen_learners), ("sac", gen_sac), ("crossq", gen_crossq), ("ddpg", gen_ddpg), ("ckpt", gen_ckpt)):
         if only and name not in only:
             continue
         out = {}
