@@ -423,10 +423,10 @@ def isolated_launch_ms(launch, device, n=16, sets=4, context=None, evict_mb=384)
     faster: that figure is reported as `frac_back_to_back`.  Consecutive launches write `sets` distinct output-tile sets."""
     if context is None:
         evict = torch.zeros(evict_mb * (1 << 20) // 4, dtype=torch.float32, device=device)
-        sink = torch.zeros(1, dtype=torch.float32, device=device)
+        sink = torch.zeros((), dtype=torch.float32, device=device)
 
         def context():
-            torch.sum(evict, out=sink[0])
+            torch.sum(evict, dim=0, out=sink)
 
     def with_launch():
         for i in range(n):

@@ -288,6 +288,39 @@ int pqlk_dpg_critic_backward(const PqlMlpDesc* d, const float* params, const flo
                              const float* dx_tanh_of, int64_t ld_tanh, const uint8_t* owner /* (B) from pqlk_dpg_loss_owner, or NULL */,
                              float* ws, int64_t ws_floats, pqlk_stream_t stream);
 
+/* The P-learner's whole backward through the frozen critic in four launches (round 4; pql_p_learner.py:54-58: actor(obs) ->
+ * -critic.get_q_min(obs, a).mean() -> .backward()).  Twin scalar-head critics whose forward is fused (hidden stack + head):
+ *   pqlk_mlp_forward_qc        the critic's forward (as pqlk_mlp_forward, out_act none) that ALSO leaves the head outputs compact,
+ *                              qc (2, B) = Q1 | Q2 (DoubleQ.get_q1_q2, mlp.py:197-199)
+ *   pqlk_dpg_backward_fused    (1) DPG loss partials, partition of the batch by the net that attained min(Q1, Q2) and the head's dX
+ *                              over compact rows in ONE launch (replaces pqlk_dpg_loss_owner + two launches of
+ *                              pqlk_dpg_critic_backward), (2) the compact dX GEMMs, (3) the action slice through tanh' TOGETHER
+ *                              WITH the actor's last-layer backward (dX, dW / db partials per 32-row tile: replaces the actor
+ *                              backward's head launch).  loss_part[pqlk_dpg_fused_loss_parts()] = partial sums of min(Q1, Q2):
+ *                              fold with scale -1 / b.  dz_a (B, ld_dz): columns [0, A) of every row are written (A = the actor's
+ *                              output width = the critic input's action columns [dx_col0, dx_col0 + A)), pad columns untouched.
+ *   pqlk_mlp_backward_tail     the rest of the actor's backward (layers below the head, slab reduction incl. the head fold,
+ *                              optional squared-norm partials as pqlk_mlp_backward_norm) over the SAME actor workspace;
+ *                              head_parts = pqlk_dpg_fused_head_parts(b), head_parts_dev = critic_ws +
+ *                              pqlk_dpg_fused_mn_offset(critic, b) floats (a device int[4]; only the partial tiles in use exist).
+ * pqlk_dpg_fused_ok = 1 when this critic / actor pair can take the path (else use pqlk_dpg_loss_owner +
+ * pqlk_dpg_critic_backward + pqlk_mlp_backward); every entry returns PQLK_E_UNSUPPORTED otherwise.
+ * critic_ws >= pqlk_dpg_backward_ws_floats(critic, b), actor_ws >= pqlk_mlp_bwd_ws_floats(actor, b, splits) floats. */
+int32_t pqlk_dpg_fused_ok(const PqlMlpDesc* critic, const PqlMlpDesc* actor, int64_t b);
+int32_t pqlk_dpg_fused_loss_parts(void);
+int32_t pqlk_dpg_fused_head_parts(int64_t b);
+int64_t pqlk_dpg_fused_mn_offset(const PqlMlpDesc* critic, int64_t b);
+int pqlk_mlp_forward_qc(const PqlMlpDesc* d, const float* params, const float* packed, int32_t stash_all, const float* x,
+                        int64_t ldx, int64_t b, float* acts, float* qc, pqlk_stream_t stream);
+int pqlk_dpg_backward_fused(const PqlMlpDesc* critic, const float* params, const float* x, int64_t ldx, int64_t b, const float* acts,
+                            const float* qc, float* dz_a, int64_t ld_dz, int32_t dx_col0, const float* a_out, int64_t ld_tanh,
+                            float* loss_part, float* critic_ws, int64_t critic_ws_floats, const PqlMlpDesc* actor,
+                            const float* actor_params, const float* actor_acts, float* actor_ws, int64_t actor_ws_floats,
+                            int32_t actor_splits, pqlk_stream_t stream);
+int pqlk_mlp_backward_tail(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b, const float* acts,
+                           float* grads, int32_t splits, float* ws, int64_t ws_floats, float* sumsq_part, int32_t* step_dev,
+                           int32_t head_parts, const int32_t* head_parts_dev, pqlk_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Losses.  Each writes dy (2, B, ld) for pqlk_mlp_backward and one scalar loss (device), via per-block
  * partials in `scratch` (>= 1024 floats) reduced in fixed order.  The scalar lands in

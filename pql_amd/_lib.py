@@ -64,6 +64,14 @@ PROTOTYPES = {
     "pqlk_mlp_backward_layers": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _F, _P, _P, _I32, _P, _I64, _I32, _I32, _P]),
     "pqlk_dpg_backward_ws_floats": (_I64, [C.POINTER(PqlMlpDesc), _I64]),
     "pqlk_dpg_critic_backward": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _I32, _P, _I64, _P, _P, _I64, _P]),
+    "pqlk_dpg_fused_ok": (_I32, [C.POINTER(PqlMlpDesc), C.POINTER(PqlMlpDesc), _I64]),
+    "pqlk_dpg_fused_loss_parts": (_I32, []),
+    "pqlk_dpg_fused_head_parts": (_I32, [_I64]),
+    "pqlk_dpg_fused_mn_offset": (_I64, [C.POINTER(PqlMlpDesc), _I64]),
+    "pqlk_mlp_forward_qc": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I32, _P, _I64, _I64, _P, _P, _P]),
+    "pqlk_dpg_backward_fused": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _P, _I64, _P, _P, _I64,
+                                          C.POINTER(PqlMlpDesc), _P, _P, _P, _I64, _I32, _P]),
+    "pqlk_mlp_backward_tail": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P, _P, _I32, _P, _P]),
     "pqlk_dpg_loss_owner": (C.c_int, [_P, _I64, _I32, _P, _I64, _P, _P, _P, _I32, _P, _P, _P]),
     "pqlk_td_mse_loss": (C.c_int, [_P, _P, _I64, _P, _P, _F, _I64, _P, _P, _P, _I32, _P, _P]),
     "pqlk_c51_bce_loss": (C.c_int, [_P, _P, _I64, _I32, _P, _P, _P, _F, _F, _F, _I64, _P, _P, _P, _I32, _P, _P, _P]),

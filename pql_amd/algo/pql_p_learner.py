@@ -168,6 +168,16 @@ class PQLPLearner:
         ws["owner"] = torch.zeros(B, dtype=torch.uint8, device=self.device)   # which net(s) own each sample's min(Q1, Q2)
         ws["bwd_a"] = torch.empty(al.bwd_ws_floats(B, ws["splits"]), **f)
         ws["scratch"] = torch.zeros(2048, **f)
+        # round 4: loss + partition + compact head in one launch, the actor's head backward inside the action-slice launch
+        # (pqlk_dpg_backward_fused: 16 -> 13 launches per step); needs the loss fold of the optimiser launch and a fused critic forward
+        K_atoms = int(getattr(self.critic, "num_atoms", 1))
+        ws["dpg_fused"] = bool(_cfg_get(self.cfg.algo, "dpg_fused", True) and self._fold_loss and K_atoms == 1 and self.pk_critic is not None
+                               and self.pk_critic.tensor is not None and L.lib.pqlk_dpg_fused_ok(C.byref(cl.desc), C.byref(al.desc), B))
+        if ws["dpg_fused"]:
+            ws["qc"] = torch.zeros((2, B), **f)
+            ws["head_parts"] = int(L.lib.pqlk_dpg_fused_head_parts(B))
+            ws["mn_ptr"] = C.c_void_p(ws["bwd_c"].data_ptr() + 4 * int(L.lib.pqlk_dpg_fused_mn_offset(C.byref(cl.desc), B)))
+            ws["loss_parts"] = int(L.lib.pqlk_dpg_fused_loss_parts())
         self._ws = ws
         self.repack()
         return ws
@@ -203,15 +213,32 @@ class PQLPLearner:
         x_act = ws["x_sa"][:, O:]
         mlp_forward_raw(al, self.actor.arena.data, ws["x_obs"], L.ACT_TANH, acts=ws["acts_a"], out2=x_act, packed=self.pk_actor,
                         stash_all=True)
+        tail = self._fused_tail   # see PQLVLearner._step_kernels
+        a_out = output_view(al, ws["acts_a"], B)  # (1, B, ld_a): tanh output, for the tanh' chain
+        if ws["dpg_fused"]:
+            L.check(L.lib.pqlk_mlp_forward_qc(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(self.pk_critic.tensor), 1, L.ptr(ws["x_sa"]),
+                                              ws["ld_sa"], B, L.ptr(ws["acts_c"]), L.ptr(ws["qc"]), st))
+            L.check(L.lib.pqlk_dpg_backward_fused(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
+                                                  L.ptr(ws["acts_c"]), L.ptr(ws["qc"]), L.ptr(ws["dz_a"]), ws["ld_a"], O, L.ptr(a_out), ws["ld_a"],
+                                                  L.ptr(ws["scratch"]), L.ptr(ws["bwd_c"]), ws["bwd_c"].numel(), C.byref(al.desc),
+                                                  L.ptr(self.actor.arena.data), L.ptr(ws["acts_a"]), L.ptr(ws["bwd_a"]), ws["bwd_a"].numel(),
+                                                  ws["splits"], st))
+            L.check(L.lib.pqlk_mlp_backward_tail(C.byref(al.desc), L.ptr(self.actor.arena.data), L.ptr(ws["x_obs"]), ws["ld_o"], B,
+                                                 L.ptr(ws["acts_a"]), L.ptr(ws["grads"]), ws["splits"], L.ptr(ws["bwd_a"]), ws["bwd_a"].numel(),
+                                                 L.ptr(self.opt.scratch) if tail else None, L.ptr(self.opt.step) if tail else None,
+                                                 ws["head_parts"], ws["mn_ptr"], st))
+            if upto_backward:
+                return
+            self._allreduce_grads(ws)
+            self._step_post(ws)
+            return
         mlp_forward_raw(cl, self.critic.arena.data, ws["x_sa"], L.ACT_NONE, acts=ws["acts_c"], packed=self.pk_critic,
                         stash_all=True)   # the dX chain through the frozen critic needs its activations (ELU')
         q = output_view(cl, ws["acts_c"], B)
         K = int(getattr(self.critic, "num_atoms", 1))
         z = getattr(self.critic, "z_atoms", None) if K > 1 else None
-        tail = self._fused_tail   # see PQLVLearner._step_kernels
         L.check(L.lib.pqlk_dpg_loss_owner(L.ptr(q), cl.ld_out, K, L.ptr(z), B, L.ptr(ws["dy_c"]), None if self._fold_loss else L.ptr(self.loss_ring),
                                           L.ptr(self.opt.step), LOSS_RING, L.ptr(ws["scratch"]), C.c_void_p(ws["owner"].data_ptr()), st))
-        a_out = output_view(al, ws["acts_a"], B)  # (1, B, ld_a): tanh output, for the tanh' chain
         # dX-only chain through the frozen critic; with scalar Q heads it runs over the samples partitioned by the net that
         # attained min(Q1, Q2): the other net's rows of every dZ are exactly zero (csrc/minnet.h)
         L.check(L.lib.pqlk_dpg_critic_backward(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
@@ -241,7 +268,8 @@ class PQLPLearner:
         if self._fold_loss:
             K = int(getattr(self.critic, "num_atoms", 1))
             apply_optimizer_fused(self.actor.layout, self.actor.arena.data, ws["grads"], self.opt, None, algo.actor_lr,
-                                  algo.max_grad_norm, 0.0, self.pk_actor, None, ws["scratch"], L.lib.pqlk_loss_parts(ws["B"], K),
+                                  algo.max_grad_norm, 0.0, self.pk_actor, None, ws["scratch"],
+                                  ws["loss_parts"] if ws["dpg_fused"] else L.lib.pqlk_loss_parts(ws["B"], K),
                                   f32_recip(ws["B"], sign=-1.0), self.loss_ring, self.device, norm_in_backward=self._fused_tail,
                                   grad_scale=1.0 / self.world)
             return

@@ -43,6 +43,7 @@ struct FusedP {
   long long head_w_off, head_b_off, head_a_off;
   const float* draw;                           // (B, head_n) standard-normal draw for HEAD_TANH_NOISE
   float* out2;                                 // optional second destination of the output (net 0), row stride ld_out2
+  float* qc;                                   // optional COMPACT copy of a scalar head's output: qc[net * B + row] (k_dpg_minnet_head's input)
   float noise_std, noise_clip;
   // optional TD head (td_dz != NULL; scalar twin-Q head, head_n == 1, two nets): the block forms the TD error of its rows from the
   // Q it has just computed and leaves the head's whole backward -- dL/dZ of the last hidden layer, the head's dW / db partial and
@@ -291,6 +292,7 @@ __device__ __forceinline__ void fused_head(const FusedP& p, const float* __restr
 #pragma unroll
       for (int w = 0; w < NW; ++w) s += fsm[part_at(((w * R + i) * 16 + e) * 64 + ln)];
       x = s + bias[c];
+      if (p.qc) p.qc[(long long)net * p.B + row0 + row] = x;   // (head_n == 1: c == 0)
       if (td) {   // N == 1: this thread holds Q(row) of this block's net.  y = r + (1-d) gamma^n min Q'  (pql_v_learner.py:104-108)
         float tq = tdt[0], tr = tdr[0], tn = tdd[0];
 #pragma unroll

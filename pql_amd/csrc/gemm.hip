@@ -907,8 +907,10 @@ static int64_t max_hidden_ld(const PqlMlpDesc* d) {
 static int64_t head_part_floats(const PqlMlpDesc* d, int64_t b) {   // room for k_skinny_bwd's per-block partials
   const int L = d->n_layers;
   const int64_t hf = (int64_t)d->dims[L] * pqlk_ld(d->dims[L - 1]) + pqlk_ld(d->dims[L]);
-  const int64_t skinny = skinny_bwd_blocks(b, d->n_nets), tiles = (b + 31) / 32;   // k_skinny_bwd's blocks; the fused forward's TD head
-  return (skinny > tiles ? skinny : tiles) * d->n_nets * hf;                         // leaves one per row tile of 32 or 64
+  // k_skinny_bwd's blocks; the fused forward's TD head leaves one per row tile of 32 or 64; the DPG slice kernel (k_dx_slice<D, QPW>)
+  // one per 32-row tile of the compact layout (2 x b rounded up to 128 rows)
+  const int64_t skinny = skinny_bwd_blocks(b, d->n_nets), tiles = 2 * pqlk_round_up(b, 128) / 32;
+  return (skinny > tiles ? skinny : tiles) * d->n_nets * hf;
 }
 
 extern "C" int64_t pqlk_mlp_bwd_ws_floats(const PqlMlpDesc* d, int64_t b, int32_t splits) {
@@ -982,6 +984,7 @@ struct FusedHead {   // output layer to run inside the fused launch (n = 0: none
   float noise_std, noise_clip;
   float* out2;
   int64_t ld_out2;
+  float* qc;   // compact copy of a scalar head's output (pqlk_mlp_forward_qc)
   // TD head (pqlk_mlp_forward_td): see FusedP
   const float* td_qt; const float* td_rew; const float* td_done; float td_gamma_n;
   float* td_dz; float* td_head_part; float* td_loss_part;
@@ -1035,6 +1038,7 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
     p.head_n = head->n; p.head_epi = head->epi; p.head_ld = (int)a_ld; p.ld_out2 = (int)head->ld_out2;
     p.head_w_off = w_off; p.head_b_off = b_off; p.head_a_off = a_off;
     p.draw = head->draw; p.out2 = head->out2; p.noise_std = head->noise_std; p.noise_clip = head->noise_clip;
+    p.qc = head->n == 1 ? head->qc : nullptr;
     if (head->td_dz) {
       p.td_qt = head->td_qt; p.td_rew = head->td_rew; p.td_done = head->td_done; p.td_gamma_n = head->td_gamma_n;
       p.td_two_over_b = 2.0f / (float)b;
@@ -1153,6 +1157,7 @@ struct ReduceP {
   long long seg_off, seg_len;   // the arena range [seg_off, seg_off + seg_len) of every net is reduced (whole arena: 0, net_stride)
   int main_blocks;
   float* sq_part; int32_t* step_dev;
+  const int* parts_dev;   // optional: only the first (parts_dev[3] + 31) / 32 head partials exist (compact tiles in use, minnet.h)
 };
 
 __global__ __launch_bounds__(256) void k_reduce_slabs(ReduceP p) {
@@ -1183,7 +1188,8 @@ __global__ __launch_bounds__(256) void k_reduce_slabs(ReduceP p) {
       const long long net = e / hq, q = e - net * hq;
       const float* hp = p.head_part + net * p.head_floats + 4 * q;
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int k = lane; k < p.head_parts; k += 64) {
+      const int parts = p.parts_dev ? min(p.head_parts, (p.parts_dev[3] + 31) / 32) : p.head_parts;
+      for (int k = lane; k < parts; k += 64) {
         const float4 t = *reinterpret_cast<const float4*>(hp + (long long)k * p.n_nets * p.head_floats);
         s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
       }
@@ -1231,7 +1237,8 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
                              const float* acts, const float* dy, float* grads, int32_t splits, float* dx,
                              int64_t ld_dx, int32_t dx_col0, int32_t dx_cols, const float* dx_tanh_of,
                              int64_t ld_tanh, float* ws, int64_t ws_floats, float* sq_part, int32_t* step_dev,
-                             pqlk_stream_t stream, const TdHead* td = nullptr, int l_hi = -1, int l_lo = 0, int head_done = 0) {
+                             pqlk_stream_t stream, const TdHead* td = nullptr, int l_hi = -1, int l_lo = 0, int head_done = 0,
+                             const int* head_parts_dev = nullptr) {
   // head_done > 0: the last layer's backward already ran inside the fused forward (pqlk_mlp_forward_td): dL/dZ of the last hidden
   // layer sits in the first dZ buffer and `head_done` row-tile partials of the head's dW / db in the partial area
   // l_hi >= 0: only layers l_hi >= l >= l_lo of the chain (dW_l, dX_l) and the slab reduction of exactly those layers (the
@@ -1381,7 +1388,7 @@ static int mlp_backward_impl(const PqlMlpDesc* d, const float* params, const flo
     w_next = net_stride;
     if (l_hi < L - 1) pqlk_mlp_layer_offsets(d, l_hi + 1, &w_next, &b_tmp);
     r.seg_off = w_lo; r.seg_len = w_next - w_lo;   // layers sit in ascending order inside a net's block
-    r.sq_part = sq_part; r.step_dev = step_dev;
+    r.sq_part = sq_part; r.step_dev = step_dev; r.parts_dev = head_parts_dev;
     r.main_blocks = reduce_main_blocks(r.seg_len * d->n_nets, sq_part != nullptr);   // with sq_part: at most 1024 + head blocks partials
     const int extra = head_blocks > 0 ? (int)((head_quads(d) + 3) / 4) : 0;
     hipLaunchKernelGGL(k_reduce_slabs, dim3(r.main_blocks + extra), dim3(256), 0, st, r);
@@ -1410,7 +1417,7 @@ static int64_t minnet_rows_cap(int64_t b) { return 2 * pqlk_round_up(b, MN_TILE)
 extern "C" int64_t pqlk_dpg_backward_ws_floats(const PqlMlpDesc* d, int64_t b) {
   if (desc_ok(d) || b <= 0) return 0;
   const int64_t dense = pqlk_mlp_bwd_ws_floats(d, b, 1);
-  const int64_t compact = 2 * minnet_rows_cap(b) * max_hidden_ld(d) + minnet_rows_cap(b) + 64;   // two dZ buffers, perm, mn
+  const int64_t compact = 2 * minnet_rows_cap(b) * max_hidden_ld(d) + 2 * minnet_rows_cap(b) + 64;   // two dZ buffers, perm, mn, tie0
   return dense > compact ? dense : compact;
 }
 
@@ -1494,6 +1501,173 @@ extern "C" int pqlk_dpg_critic_backward(const PqlMlpDesc* d, const float* params
     if (rc) return rc;
   }
   return PQLK_OK;
+}
+
+// ---- round 4: the P-learner's backward through the frozen critic in FOUR launches (was seven) -----------------------------------
+// k_dpg_minnet_head (DPG loss partials + partition + compact head, off the compact Q the fused forward left), two compact dX GEMMs,
+// k_dx_slice<D, QPW> (action slice through tanh' + the ACTOR's head backward).  Needs: twin scalar-head critic that the min-net
+// chain takes (minnet_ok) with a fused forward + fused head (so that qc exists), first hidden width a multiple of 128 (slice ring),
+// an actor whose head is <= 16 wide over 128 or 256 inputs and whose backward takes per-tile head partials (head_is_fused).
+static bool dpg_fused_ok(const PqlMlpDesc* c, const PqlMlpDesc* a, int64_t b) {
+  if (desc_ok(c) || desc_ok(a) || b <= 0 || b > 131072) return false;
+  const int Lc = c->n_layers, La = a->n_layers;
+  if (c->n_nets != 2 || Lc < 3 || c->dims[Lc] != 1 || a->n_nets != 1 || La < 2) return false;
+  if (!skinny_bwd_ok(1, (int)pqlk_ld(c->dims[Lc - 1]))) return false;
+  for (int l = 1; l < Lc; ++l)
+    if (c->dims[l] % 32 != 0) return false;
+  for (int l = 1; l < Lc - 1; ++l)
+    if (c->dims[l] % 128 != 0) return false;
+  if (!fusable(c, nullptr) || !head_fusable(c) || getenv("PQLK_NO_FUSED_HEAD")) return false;
+  const int A = a->dims[La];
+  if (A > 16 || c->dims[0] < A || !head_is_fused(a) || !dx_slice_head_ok(A, (int)pqlk_ld(a->dims[La - 1])) || a->dims[La - 1] % 32 != 0) return false;
+  return true;
+}
+
+extern "C" int32_t pqlk_dpg_fused_ok(const PqlMlpDesc* critic, const PqlMlpDesc* actor, int64_t b) {
+  return critic && actor && dpg_fused_ok(critic, actor, b) ? 1 : 0;
+}
+
+// number of loss partials pqlk_dpg_backward_fused leaves (sums of min(Q1, Q2); fold with scale -1 / b)
+extern "C" int32_t pqlk_dpg_fused_loss_parts(void) { return DPG_LOSS_PARTS; }
+
+// number of head partials (one per compact 32-row tile) pqlk_mlp_backward_tail has to be told about
+extern "C" int32_t pqlk_dpg_fused_head_parts(int64_t b) { return b > 0 ? (int32_t)(minnet_rows_cap(b) / 32) : 0; }
+
+// The twin scalar-head critic's forward that ALSO leaves the head outputs compact: qc (2, B) = Q1 | Q2 (mlp.py:186-203).
+extern "C" int pqlk_mlp_forward_qc(const PqlMlpDesc* d, const float* params, const float* packed, int32_t stash_all, const float* x,
+                                   int64_t ldx, int64_t b, float* acts, float* qc, pqlk_stream_t stream) {
+  int rc = desc_ok(d);
+  if (rc) return rc;
+  PQLK_REQUIRE(params && packed && x && acts && qc, PQLK_E_NULL);
+  PQLK_REQUIRE(b > 0 && b < (1LL << 30), PQLK_E_SHAPE);
+  PQLK_REQUIRE(ldx % 32 == 0 && ldx >= pqlk_ld(d->dims[0]), PQLK_E_ALIGN);
+  PQLK_REQUIRE(pqlk_aligned16(params) && pqlk_aligned16(packed) && pqlk_aligned16(x) && pqlk_aligned16(acts) && pqlk_aligned16(qc), PQLK_E_ALIGN);
+  PQLK_REQUIRE(d->dims[d->n_layers] == 1 && fusable(d, nullptr) && head_fusable(d) && !getenv("PQLK_NO_FUSED_HEAD"), PQLK_E_UNSUPPORTED);
+  FusedHead head = {};
+  head.n = 1; head.epi = PQLK_ACT_NONE; head.qc = qc;
+  return launch_fused_hidden(d, params, packed, x, ldx, b, acts, stash_all ? 1 : 0, pqlk_s(stream), &head);
+}
+
+// DPG loss + the dX chain through the frozen critic + the actor's head backward (pql_p_learner.py:55-58).
+//   in : critic params / activation stash (pqlk_mlp_forward_qc, stash_all) / qc; x = the critic's input [obs | pi(obs)];
+//        a_out = tanh output of the actor (B, ld_tanh); actor params / activation stash
+//   out: loss_part[pqlk_dpg_fused_loss_parts()]; dz_a (B, ld_dz) columns [0, A) = dL/d(pre-tanh action) (pad columns untouched);
+//        actor_ws (the workspace of the actor's pqlk_mlp_backward_tail): dL/dZ of the actor's last hidden layer + one head partial
+//        per compact 32-row tile.  Follow with pqlk_mlp_backward_tail(actor, ..., pqlk_dpg_fused_head_parts(b), critic_ws).
+// critic_ws: pqlk_dpg_backward_ws_floats(critic, b) floats; its perm / mn block stays valid for the tail call.
+extern "C" int pqlk_dpg_backward_fused(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b, const float* acts,
+                                       const float* qc, float* dz_a, int64_t ld_dz, int32_t dx_col0, const float* a_out, int64_t ld_tanh,
+                                       float* loss_part, float* ws, int64_t ws_floats, const PqlMlpDesc* ad, const float* a_params,
+                                       const float* a_acts, float* a_ws, int64_t a_ws_floats, int32_t a_splits, pqlk_stream_t stream) {
+  PQLK_REQUIRE(d && ad && params && x && acts && qc && dz_a && a_out && loss_part && ws && a_params && a_acts && a_ws, PQLK_E_NULL);
+  PQLK_REQUIRE(dpg_fused_ok(d, ad, b), PQLK_E_UNSUPPORTED);
+  PQLK_REQUIRE(ws_floats >= pqlk_dpg_backward_ws_floats(d, b), PQLK_E_WORKSPACE);
+  PQLK_REQUIRE(a_splits >= 1 && a_splits <= 64 && a_ws_floats >= pqlk_mlp_bwd_ws_floats(ad, b, a_splits), PQLK_E_WORKSPACE);
+  const int L = d->n_layers, La = ad->n_layers, A = ad->dims[La];
+  PQLK_REQUIRE(ld_dz % 32 == 0 && ld_dz >= A && ld_tanh >= A && dx_col0 >= 0 && dx_col0 + A <= d->dims[0], PQLK_E_RANGE);
+  PQLK_REQUIRE(ldx % 32 == 0 && ldx >= pqlk_ld(d->dims[0]), PQLK_E_ALIGN);
+  PQLK_REQUIRE(pqlk_aligned16(qc) && pqlk_aligned16(ws) && pqlk_aligned16(a_ws) && pqlk_aligned16(acts) && pqlk_aligned16(a_acts), PQLK_E_ALIGN);
+  const int64_t net_stride = pqlk_mlp_net_stride(d);
+  const int64_t rows_cap = minnet_rows_cap(b), mld = max_hidden_ld(d);
+  float* dz[2] = {ws, ws + rows_cap * mld};
+  int* perm = reinterpret_cast<int*>(ws + 2 * rows_cap * mld);
+  int* mn = perm + rows_cap;          // 64 ints
+  int* tie0 = mn + 64;                // rows_cap ints (pqlk_dpg_backward_ws_floats)
+  hipStream_t st = pqlk_s(stream);
+  int rc;
+  // 1. loss partials + partition + compact head
+  {
+    int64_t w_off, b_off, h_off, h_ld;
+    pqlk_mlp_layer_offsets(d, L - 1, &w_off, &b_off);
+    pqlk_mlp_act_offset(d, b, 0, L - 2, &h_off, &h_ld);
+    DpgHeadP h = {};
+    h.qc = qc; h.B = b;
+    h.H = acts + h_off; h.sH = b * h_ld; h.ldh = (int)h_ld;
+    h.W = params + w_off; h.sW = net_stride;
+    h.C = dz[0]; h.K = (int)pqlk_ld(d->dims[L - 1]);
+    h.perm = perm; h.tie0 = tie0; h.perm_len = rows_cap; h.mn = mn;
+    h.loss_part = loss_part; h.gb = -1.0f / (float)b;
+    int64_t blocks = rows_cap / 16;
+    if (blocks > 256) blocks = 256;
+    if (blocks < 1) blocks = 1;
+    h.rows_cap_blk = (int)((rows_cap + blocks - 1) / blocks);
+    const size_t sh = ((size_t)2 * h.rows_cap_blk + (size_t)2 * h.K) * sizeof(float);
+    hipLaunchKernelGGL(k_dpg_minnet_head, dim3((unsigned)blocks), dim3(1024), sh, st, h);
+    PQLK_LAUNCH_CHECK();
+  }
+  // 2. hidden layers over compact rows (as pqlk_dpg_critic_backward)
+  int flip = 0;
+  for (int l = L - 2; l >= 1; --l) {
+    int64_t w_off, b_off, a_off, a_ld;
+    pqlk_mlp_layer_offsets(d, l, &w_off, &b_off);
+    pqlk_mlp_act_offset(d, b, 0, l - 1, &a_off, &a_ld);
+    GemmP p = {};
+    p.A = dz[flip]; p.lda = (int)pqlk_ld(d->dims[l + 1]); p.sA = 0;
+    p.B = params + w_off; p.ldb = (int)pqlk_ld(d->dims[l]); p.sB = net_stride;
+    p.C = dz[flip ^ 1]; p.ldc = (int)pqlk_ld(d->dims[l]); p.sC = 0;
+    p.aux = acts + a_off; p.ldaux = (int)a_ld; p.sAux = b * a_ld;
+    p.M = (int)rows_cap; p.N = d->dims[l]; p.K = d->dims[l + 1];
+    p.ncols_store = p.ldc;
+    p.groups = 2; p.zsum = 0; p.epi = EPI_DELU;
+    p.perm = perm; p.mn = mn;
+    rc = launch_gemm<MODE_DX, 128, 64, EPI_DELU>(p, 1, st);
+    if (rc) return rc;
+    flip ^= 1;
+  }
+  // 3. action slice through tanh' + the actor head's backward
+  {
+    int64_t w_off, b_off, aw_off, ab_off, ah_off, ah_ld;
+    pqlk_mlp_layer_offsets(d, 0, &w_off, &b_off);
+    pqlk_mlp_layer_offsets(ad, La - 1, &aw_off, &ab_off);
+    pqlk_mlp_act_offset(ad, b, 0, La - 2, &ah_off, &ah_ld);
+    GemmP p = {};
+    p.A = dz[flip]; p.lda = (int)pqlk_ld(d->dims[1]); p.sA = 0;
+    p.B = params + w_off; p.ldb = (int)pqlk_ld(d->dims[0]); p.sB = net_stride;
+    p.C = dz_a; p.ldc = (int)ld_dz; p.sC = 0;
+    p.M = (int)rows_cap; p.N = d->dims[0]; p.K = d->dims[1];
+    p.ncols_store = p.ldb;
+    p.groups = 1; p.zsum = 1;
+    p.epi = EPI_DTANH_SLICE; p.aux = a_out; p.ldaux = (int)ld_tanh; p.col0 = dx_col0; p.ncol = A;
+    p.perm = perm; p.mn = mn;
+    PQLK_REQUIRE(dx_slice_ok(p), PQLK_E_UNSUPPORTED);
+    SliceHeadX hx = {};
+    hx.tie0 = tie0;
+    hx.Hh = a_acts + ah_off; hx.ldh = (int)ah_ld;
+    hx.Wh = a_params + aw_off; hx.N = A; hx.Kh = (int)pqlk_ld(ad->dims[La - 1]);
+    PQLK_REQUIRE(ah_ld == hx.Kh, PQLK_E_SHAPE);
+    hx.dXh = a_ws;   // mlp_backward_impl's first dZ buffer
+    hx.part = a_ws + 2 * (int64_t)ad->n_nets * b * max_hidden_ld(ad) + (int64_t)a_splits * pqlk_mlp_param_floats(ad);
+    hx.part_floats = pqlk_mlp_net_stride(ad) - aw_off;
+    rc = launch_dx_slice(p, st, &hx);
+    if (rc) return rc;
+  }
+  return PQLK_OK;
+}
+
+// The rest of a backward whose LAST layer has already been done elsewhere (pqlk_dpg_backward_fused: dL/dZ of the last hidden layer in
+// the workspace's first dZ buffer, `head_parts` per-tile partials of the head's dW / db behind the slabs, of which only the first
+// (head_parts_dev[3] + 31) / 32 exist when head_parts_dev is given): dW / dX of the layers below, slab reduction incl. the head
+// fold, and -- with sumsq_part / step_dev -- the squared-norm partials of pqlk_mlp_backward_norm.
+extern "C" int pqlk_mlp_backward_tail(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b, const float* acts,
+                                      float* grads, int32_t splits, float* ws, int64_t ws_floats, float* sumsq_part, int32_t* step_dev,
+                                      int32_t head_parts, const int32_t* head_parts_dev, pqlk_stream_t stream) {
+  int rc = desc_ok(d);
+  if (rc) return rc;
+  PQLK_REQUIRE(grads, PQLK_E_NULL);
+  PQLK_REQUIRE((sumsq_part == nullptr) == (step_dev == nullptr), PQLK_E_NULL);
+  PQLK_REQUIRE(head_parts > 0 && head_is_fused(d), PQLK_E_UNSUPPORTED);
+  const int L = d->n_layers;
+  const int64_t hf = (int64_t)d->dims[L] * pqlk_ld(d->dims[L - 1]) + pqlk_ld(d->dims[L]);
+  PQLK_REQUIRE((int64_t)head_parts * d->n_nets * hf <= head_part_floats(d, b), PQLK_E_WORKSPACE);
+  return mlp_backward_impl(d, params, x, ldx, b, acts, nullptr, grads, splits, nullptr, 0, 0, 0, nullptr, 0, ws, ws_floats, sumsq_part,
+                           step_dev, stream, nullptr, -1, 0, (int)head_parts, head_parts_dev);
+}
+
+// float offset of mn = {c0, c1, first row of net 1, compact rows in use} inside pqlk_dpg_backward_fused's critic workspace: the
+// `head_parts_dev` of the pqlk_mlp_backward_tail call that follows it
+extern "C" int64_t pqlk_dpg_fused_mn_offset(const PqlMlpDesc* critic, int64_t b) {
+  if (desc_ok(critic) || b <= 0) return -1;
+  return 2 * minnet_rows_cap(b) * max_hidden_ld(critic) + minnet_rows_cap(b);
 }
 
 extern "C" int pqlk_mlp_backward(const PqlMlpDesc* d, const float* params, const float* x, int64_t ldx, int64_t b,

@@ -184,8 +184,27 @@ static int launch_fwd_narrow(const GemmP& p, int groups, hipStream_t st) {
 // with k fastest, i.e. the transpose of the row-major slice: each wave stages ITS quarter transposed into LDS once
 // (16-B global loads when col0 is 16-B aligned), batch-side fragments (dY rows) come straight from global.
 
-template <int D>   // ring depth; K8 % D == 0
-__global__ __launch_bounds__(256) void k_dx_slice(GemmP p) {
+// Round 4 (QPW > 0): the ACTOR's head backward rides in the same launch.  The slice's output row -- dL/d(pre-tanh action) of one
+// sample, <= 16 floats -- is all the actor's last layer needs: dX_h = (dz W_h) * ELU'(H_h), dW_h += dz^T H_h, db_h += dz, a row-local
+// chain that k_skinny_bwd<16> ran as a launch of its own after the (B, 16) matrix had gone through HBM (17.0 + 13.9 us at batch
+// 8192).  The tile's 32 dz rows stay in LDS; wave w takes the column quads [w QPW, (w + 1) QPW) of the K_h = 16 QPW inputs, its
+// lanes = QPW quads x (64 / QPW) row groups of QPW / 2 rows; the row groups are folded by a fixed xor-shuffle tree and every tile
+// leaves ONE partial (N x K_h weights, then 32 bias floats: k_skinny_bwd's format) that k_reduce_slabs folds in tile order.
+// Ties (min(Q1, Q2) attained by both nets: the sample sits in both runs, tie0[] of k_dpg_minnet_head) are finished in the run-1
+// tile -- the lane that owns the row adds net 0's contribution from the sample's run-0 row of dZ with a plain dot product (an
+// exact tie of two fp32 network outputs is a once-in-a-million-samples event) -- and skipped in the run-0 tile: every batch row is
+// written exactly once, no atomics, no zero-fill.
+struct SliceHeadX {
+  const int* tie0;
+  const float* Hh; int ldh;        // (B, ldh) the actor's last hidden activations
+  const float* Wh; int N, Kh;      // (N, Kh) head weights
+  float* dXh;                      // (B, Kh) dL/dZ of the actor's last hidden layer
+  float* part; long long part_floats;
+};
+
+template <int D, int QPW = 0>   // ring depth; K8 % D == 0
+// (waves_per_eu 2: two blocks per CU -- the 66-KB weight stage allows exactly two -- so at most 256 registers per lane, AGPRs included)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_dx_slice(GemmP p, SliceHeadX x) {
   typedef float acc_t __attribute__((ext_vector_type(16)));
   extern __shared__ __attribute__((aligned(16))) float dxs_lds[];   // 4 waves x 32 columns x (kq + 4)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -200,6 +219,37 @@ __global__ __launch_bounds__(256) void k_dx_slice(GemmP p) {
     cnet = m0 >= p.mn[2] ? 1 : 0;
   }
   const float* Bw = p.B + (long long)cnet * p.sB;      // (groups = 1 in compact mode, so the g * sB terms below vanish)
+  // QPW > 0: what the head phase at the END of the kernel needs from memory is requested HERE, ahead of the weight staging and the
+  // MFMA loop, so that its latency (batch row -> activation row of the actor's last hidden layer, two dependent loads) is not the
+  // kernel's tail: lane (quad qg, row group rg) of wave w takes the column quad w QPW + qg of tile rows rg RPL .. rg RPL + RPL - 1
+  constexpr int HQ = QPW > 0 ? QPW : 16, HRPL = 32 / (64 / HQ);
+  float4 hxv[QPW > 0 ? HRPL : 1];
+  int hrow[QPW > 0 ? HRPL : 1];
+  float haux[8];      // wave 0: tanh outputs of this lane's (row, column) slots
+  int horow = -1, ht0 = -1;
+  if (QPW > 0) {
+    const int hq = wave * HQ + lane % HQ, hrg = lane / HQ;
+#pragma unroll
+    for (int j = 0; j < HRPL; ++j) {
+      const int rr = m0 + hrg * HRPL + j;
+      int m = p.perm[rr];
+      if (x.tie0[rr] == -2) m = -1;   // the run-0 copy of a tie sample: its run-1 tile writes the row
+      hrow[j] = m;
+    }
+#pragma unroll
+    for (int j = 0; j < HRPL; ++j)
+      hxv[j] = hrow[j] >= 0 ? *reinterpret_cast<const float4*>(x.Hh + (long long)hrow[j] * x.ldh + 4 * hq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wave == 0) {
+      horow = p.perm[m0 + r];
+      ht0 = x.tie0[m0 + r];
+      if (ht0 == -2) horow = -1;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = 8 * (e >> 2) + 4 * h + (e & 3);
+        haux[e] = (horow >= 0 && c < p.ncol) ? p.aux[(long long)horow * p.ldaux + c] : 0.f;
+      }
+    }
+  }
   const int ktot = p.groups * p.K;          // p.K = hidden width (multiple of 32)
   const int kq = ktot >> 2;                 // reduction elements of this wave; multiple of 8
   const int kbeg = wave * kq;
@@ -273,21 +323,118 @@ __global__ __launch_bounds__(256) void k_dx_slice(GemmP p) {
 #pragma unroll
   for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = (acc4[0][e] + acc4[1][e]) + (acc4[2][e] + acc4[3][e]);
   __syncthreads();
-  if (wave != 0) return;
-  int orow = m0 + r;
-  if (orow >= p.M) return;
-  if (p.perm) {
-    orow = p.perm[orow];
-    if (orow < 0) return;   // pad row of the compact layout
-  }
+  if (QPW == 0) {
+    if (wave != 0) return;
+    int orow = m0 + r;
+    if (orow >= p.M) return;
+    if (p.perm) {
+      orow = p.perm[orow];
+      if (orow < 0) return;   // pad row of the compact layout
+    }
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const float s = ((red[e * 64 + lane] + red[(16 + e) * 64 + lane]) + red[(32 + e) * 64 + lane]) + red[(48 + e) * 64 + lane];
-    const int c = 8 * (e >> 2) + 4 * h + (e & 3);
-    if (c < p.ncol) {
-      const float a = p.aux[(long long)orow * p.ldaux + c];
-      if (p.perm) atomicAdd(&p.C[(long long)orow * p.ldc + c], s * (1.f - a * a));
-      else p.C[(long long)orow * p.ldc + c] = s * (1.f - a * a);
+    for (int e = 0; e < 16; ++e) {
+      const float s = ((red[e * 64 + lane] + red[(16 + e) * 64 + lane]) + red[(32 + e) * 64 + lane]) + red[(48 + e) * 64 + lane];
+      const int c = 8 * (e >> 2) + 4 * h + (e & 3);
+      if (c < p.ncol) {
+        const float a = p.aux[(long long)orow * p.ldaux + c];
+        if (p.perm) atomicAdd(&p.C[(long long)orow * p.ldc + c], s * (1.f - a * a));
+        else p.C[(long long)orow * p.ldc + c] = s * (1.f - a * a);
+      }
+    }
+    return;
+  }
+  // ---- QPW > 0: compact rows only (host), ncol <= 16.  dz tile -> LDS, then the actor head's backward
+  float* dzt = dxs_lds + 4096;                                  // [32][20] behind the 16-KB reduction buffer
+  if (wave == 0) {
+    const int orow = horow, t0 = ht0;     // (tile rows < rows_cap: host M = rows_cap, a multiple of 32)
+    float sv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sv[e] = ((red[e * 64 + lane] + red[(16 + e) * 64 + lane]) + red[(32 + e) * 64 + lane]) + red[(48 + e) * 64 + lane];
+    if (orow >= 0 && t0 >= 0) {   // tie: + net 0's contribution, from the sample's run-0 row of dZ (cnet == 1 here)
+      float s0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float* ar = p.A + (long long)t0 * p.lda;
+      for (int k = 0; k < p.K; ++k) {
+        const float av = ar[k];
+        const float* wr = p.B + (long long)k * p.ldb + p.col0;   // net 0's weights
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = 8 * (e >> 2) + 4 * h + (e & 3);
+          if (c < p.ncol) s0[e] += av * wr[c];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sv[e] += s0[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = 8 * (e >> 2) + 4 * h + (e & 3);
+      float dz = 0.f;
+      if (orow >= 0 && c < p.ncol) {
+        dz = sv[e] * (1.f - haux[e] * haux[e]);
+        p.C[(long long)orow * p.ldc + c] = dz;
+      }
+      dzt[r * 20 + c] = dz;
+    }
+  }
+  __syncthreads();
+  if (QPW > 0) {
+    constexpr int Q = HQ, RPL = HRPL;
+    const int qg = lane % Q, rg = lane / Q;
+    const int q = wave * Q + qg;                 // this lane's column quad of the K_h = 16 Q inputs
+    float* out = x.part + (long long)blockIdx.x * x.part_floats;
+    // the N <= 16 outputs in two passes of 8 (weights + dW accumulators of 8 outputs: 64 registers instead of 128, two blocks per CU)
+    float4 asum[RPL];
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) asum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma nounroll   // (unrolled, both passes' weight loads are hoisted to the top: 316 VGPRs)
+    for (int n0 = 0; n0 < 16; n0 += 8) {
+      if (n0 < x.N) {   // block-uniform
+        float4 wq[8], acc[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          wq[n] = n0 + n < x.N ? *reinterpret_cast<const float4*>(x.Wh + (long long)(n0 + n) * x.Kh + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+          acc[n] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+          const float* dr = dzt + (rg * RPL + j) * 20 + n0;
+          const float4 d0 = *reinterpret_cast<const float4*>(dr), d1 = *reinterpret_cast<const float4*>(dr + 4);
+          const float dn[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};   // (zero beyond N and for rows with nothing to do)
+          const float4 xx = hxv[j];
+#pragma unroll
+          for (int n = 0; n < 8; ++n) {
+            asum[j].x += dn[n] * wq[n].x; asum[j].y += dn[n] * wq[n].y; asum[j].z += dn[n] * wq[n].z; asum[j].w += dn[n] * wq[n].w;
+            acc[n].x += dn[n] * xx.x; acc[n].y += dn[n] * xx.y; acc[n].z += dn[n] * xx.z; acc[n].w += dn[n] * xx.w;
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+          if (n0 + n < x.N) {
+            float4 v = acc[n];
+#pragma unroll
+            for (int o = Q; o < 64; o <<= 1) {   // fold the row groups: fixed xor tree
+              v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64); v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+            }
+            if (rg == 0) *reinterpret_cast<float4*>(out + (long long)(n0 + n) * x.Kh + 4 * q) = v;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) {
+      float4 a = asum[j];
+      const float4 xx = hxv[j];
+      a.x = xx.x > 0.f ? a.x : a.x * (xx.x + 1.f);   // ELU'(h) = h + 1 for h <= 0
+      a.y = xx.y > 0.f ? a.y : a.y * (xx.y + 1.f);
+      a.z = xx.z > 0.f ? a.z : a.z * (xx.z + 1.f);
+      a.w = xx.w > 0.f ? a.w : a.w * (xx.w + 1.f);
+      if (hrow[j] >= 0) *reinterpret_cast<float4*>(x.dXh + (long long)hrow[j] * x.Kh + 4 * q) = a;
+    }
+    if (wave == 0 && lane < 32) {   // db (rows ascending) + the zero pad of the bias block
+      float db = 0.f;
+      if (lane < x.N)
+        for (int rr = 0; rr < 32; ++rr) db += dzt[rr * 20 + lane];
+      out[(long long)x.N * x.Kh + lane] = db;
     }
   }
 }
@@ -302,12 +449,18 @@ static bool dx_slice_ok(const GemmP& p) {
          dx_slice_lds(p) <= 160 * 1024;
 }
 
-static int launch_dx_slice(const GemmP& p, hipStream_t st) {
-  const size_t shmem = dx_slice_lds(p);
+// the actor head rides along when its input width is 16 QPW floats with QPW in {8, 16} (128 / 256: both BASELINE hidden shapes)
+static bool dx_slice_head_ok(int n_out, int k_h) { return n_out >= 1 && n_out <= 16 && (k_h == 128 || k_h == 256); }
+
+static int launch_dx_slice(const GemmP& p, hipStream_t st, const SliceHeadX* head = nullptr) {
+  size_t shmem = dx_slice_lds(p);
+  if (head && shmem < 16384 + 4096) shmem = 16384 + 4096;   // reduction buffer + dz tile + row table
   static PqlkPerDeviceOnce attr_once;
   if (int rc = attr_once.run([&] {
         for (const void* k : {reinterpret_cast<const void*>(&k_dx_slice<16>), reinterpret_cast<const void*>(&k_dx_slice<4>),
-                              reinterpret_cast<const void*>(&k_dx_slice<1>)}) {
+                              reinterpret_cast<const void*>(&k_dx_slice<1>), reinterpret_cast<const void*>(&k_dx_slice<16, 16>),
+                              reinterpret_cast<const void*>(&k_dx_slice<16, 8>), reinterpret_cast<const void*>(&k_dx_slice<4, 16>),
+                              reinterpret_cast<const void*>(&k_dx_slice<4, 8>)}) {
           hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           if (e != hipSuccess) return -(int)e;
         }
@@ -316,9 +469,23 @@ static int launch_dx_slice(const GemmP& p, hipStream_t st) {
     return rc;
   const int K8 = p.groups * p.K / 32;   // reduction steps of 8 per wave
   const dim3 grid((unsigned)((p.M + 31) / 32)), block(256);
-  if (K8 % 16 == 0) hipLaunchKernelGGL(k_dx_slice<16>, grid, block, shmem, st, p);
-  else if (K8 % 4 == 0) hipLaunchKernelGGL(k_dx_slice<4>, grid, block, shmem, st, p);
-  else hipLaunchKernelGGL(k_dx_slice<1>, grid, block, shmem, st, p);
+  if (head) {   // (host: compact mode, ncol <= 16, K8 % 4 == 0 -- hidden widths are multiples of 128 there)
+    if (K8 % 4 != 0 || !p.perm || p.ncol > 16 || !dx_slice_head_ok(head->N, head->Kh)) return PQLK_E_UNSUPPORTED;
+    const bool wide = head->Kh == 256;
+    if (K8 % 16 == 0) {
+      if (wide) hipLaunchKernelGGL((k_dx_slice<16, 16>), grid, block, shmem, st, p, *head);
+      else hipLaunchKernelGGL((k_dx_slice<16, 8>), grid, block, shmem, st, p, *head);
+    } else {
+      if (wide) hipLaunchKernelGGL((k_dx_slice<4, 16>), grid, block, shmem, st, p, *head);
+      else hipLaunchKernelGGL((k_dx_slice<4, 8>), grid, block, shmem, st, p, *head);
+    }
+    PQLK_LAUNCH_CHECK();
+    return PQLK_OK;
+  }
+  const SliceHeadX none = {};
+  if (K8 % 16 == 0) hipLaunchKernelGGL(k_dx_slice<16>, grid, block, shmem, st, p, none);
+  else if (K8 % 4 == 0) hipLaunchKernelGGL(k_dx_slice<4>, grid, block, shmem, st, p, none);
+  else hipLaunchKernelGGL(k_dx_slice<1>, grid, block, shmem, st, p, none);
   PQLK_LAUNCH_CHECK();
   return PQLK_OK;
 }

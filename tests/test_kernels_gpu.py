@@ -887,6 +887,84 @@ def test_dpg_critic_backward_minnet_matches_dense_chain(dev, hidden, B):
         assert torch.equal(comp, comp_q)   # ownership from the byte array == ownership derived from the Q heads
 
 
+@pytest.mark.parametrize("hidden,A,B", [([512, 512, 256], 16, 8192), ([512, 256, 128], 16, 1000), ([512, 256, 128], 2, 256), ([256, 128, 128], 5, 333)])
+def test_dpg_backward_fused_matches_the_separate_launches(dev, hidden, A, B):
+    """Round 4: pqlk_mlp_forward_qc + pqlk_dpg_backward_fused + pqlk_mlp_backward_tail (DPG loss, partition and compact head in one
+    launch off the compact Q; the actor's head backward inside the action-slice launch) against the launches they replace
+    (pqlk_dpg_loss_owner + pqlk_dpg_critic_backward + pqlk_mlp_backward): same loss, same action gradient, same actor gradient up to
+    the reassociation of sums -- on natural Q values, with exact ties on every 7th sample (both nets own the sample: finished in
+    the run-1 tile) and with every sample owned by net 1 (run 0 empty)."""
+    from pql_amd import _lib as L
+    from pql_amd.models.mlp import ArenaLayout, PackedWeights, default_splits, mlp_forward_raw, output_view
+    O = 88
+    cl, al = ArenaLayout([O + A, *hidden, 1], 2), ArenaLayout([O, *hidden, A], 1)
+    assert L.lib.pqlk_dpg_fused_ok(C.byref(cl.desc), C.byref(al.desc), B) == 1
+    g = torch.Generator(device=dev).manual_seed(B)
+    carena, aarena = torch.zeros(cl.total, device=dev), torch.zeros(al.total, device=dev)
+    for lay, arena in ((cl, carena), (al, aarena)):
+        for n in range(lay.n_nets):
+            for l in range(lay.n_layers):
+                bound = 1.0 / np.sqrt(lay.dims[l])
+                lay.weight(arena, n, l).copy_((torch.rand(lay.weight(arena, n, l).shape, device=dev, generator=g) * 2 - 1) * bound)
+                lay.bias(arena, n, l).copy_((torch.rand(lay.dims[l + 1], device=dev, generator=g) * 2 - 1) * bound)
+    x_obs = torch.zeros((B, al.ld_in), device=dev); x_obs[:, :O] = torch.randn((B, O), device=dev, generator=g)
+    x_sa = torch.zeros((B, cl.ld_in), device=dev); x_sa[:, :O] = x_obs[:, :O]
+    pkc, pka = PackedWeights(cl, dev).refresh(carena), PackedWeights(al, dev).refresh(aarena)
+    acts_a = mlp_forward_raw(al, aarena, x_obs, L.ACT_TANH, out2=x_sa[:, O:], packed=pka, stash_all=True)
+    a_out = output_view(al, acts_a, B)
+    ld_a, splits, st = L.ld(A), default_splits(B), L.stream(dev)
+    acts_c = torch.empty(cl.acts_floats(B), device=dev)
+    qc = torch.zeros((2, B), device=dev)
+    L.check(L.lib.pqlk_mlp_forward_qc(C.byref(cl.desc), L.ptr(carena), L.ptr(pkc.tensor), 1, L.ptr(x_sa), cl.ld_in, B, L.ptr(acts_c), L.ptr(qc), st))
+    acts_ref = mlp_forward_raw(cl, carena, x_sa, L.ACT_NONE, packed=pkc, stash_all=True)
+    assert torch.equal(acts_c, acts_ref)                                    # the compact copy changes nothing else
+    assert torch.equal(qc, output_view(cl, acts_c, B)[:, :, 0])
+    for case in ("natural", "ties", "all_net1"):
+        q = output_view(cl, acts_c, B)
+        if case == "ties":
+            q[1, ::7, 0] = q[0, ::7, 0]
+        elif case == "all_net1":
+            q[1, :, 0] = q[0, :, 0] - 1.0
+        qc.copy_(q[:, :, 0])
+        # ---- the separate launches
+        dy = torch.zeros((2, B, cl.ld_out), device=dev); owner = torch.zeros(B, dtype=torch.uint8, device=dev)
+        ring = torch.zeros(5, device=dev); slot = torch.zeros(1, dtype=torch.int32, device=dev); scratch = torch.zeros(2048, device=dev)
+        L.check(L.lib.pqlk_dpg_loss_owner(L.ptr(q), cl.ld_out, 1, None, B, L.ptr(dy), L.ptr(ring), L.ptr(slot), 5, L.ptr(scratch),
+                                          C.c_void_p(owner.data_ptr()), st))
+        dz_ref = torch.zeros((1, B, ld_a), device=dev)
+        ws_c = torch.empty(int(L.lib.pqlk_dpg_backward_ws_floats(C.byref(cl.desc), B)), device=dev)
+        L.check(L.lib.pqlk_dpg_critic_backward(C.byref(cl.desc), L.ptr(carena), L.ptr(x_sa), cl.ld_in, B, L.ptr(acts_c), L.ptr(dy), L.ptr(dz_ref),
+                                               ld_a, O, A, L.ptr(a_out), ld_a, C.c_void_p(owner.data_ptr()), L.ptr(ws_c), ws_c.numel(), st))
+        g_ref = torch.zeros(al.total, device=dev)
+        ws_a = torch.empty(al.bwd_ws_floats(B, splits), device=dev)
+        L.check(L.lib.pqlk_mlp_backward(C.byref(al.desc), L.ptr(aarena), L.ptr(x_obs), al.ld_in, B, L.ptr(acts_a), L.ptr(dz_ref), L.ptr(g_ref),
+                                        splits, None, 0, 0, 0, None, 0, L.ptr(ws_a), ws_a.numel(), st))
+        # ---- the fused launches (fresh workspaces, poisoned: nothing may depend on what they held)
+        dz = torch.zeros((1, B, ld_a), device=dev); dz[0, :, :A] = 3.0
+        ws_c2 = torch.full_like(ws_c, float("nan")); ws_a2 = torch.full_like(ws_a, float("nan"))
+        parts = torch.full((64,), float("nan"), device=dev)
+        L.check(L.lib.pqlk_dpg_backward_fused(C.byref(cl.desc), L.ptr(carena), L.ptr(x_sa), cl.ld_in, B, L.ptr(acts_c), L.ptr(qc), L.ptr(dz), ld_a, O,
+                                              L.ptr(a_out), ld_a, L.ptr(parts), L.ptr(ws_c2), ws_c2.numel(), C.byref(al.desc), L.ptr(aarena),
+                                              L.ptr(acts_a), L.ptr(ws_a2), ws_a2.numel(), splits, st))
+        g_new = torch.full((al.total,), float("nan"), device=dev)
+        mn_ptr = C.c_void_p(ws_c2.data_ptr() + 4 * int(L.lib.pqlk_dpg_fused_mn_offset(C.byref(cl.desc), B)))
+        L.check(L.lib.pqlk_mlp_backward_tail(C.byref(al.desc), L.ptr(aarena), L.ptr(x_obs), al.ld_in, B, L.ptr(acts_a), L.ptr(g_new), splits,
+                                             L.ptr(ws_a2), ws_a2.numel(), None, None, int(L.lib.pqlk_dpg_fused_head_parts(B)), mn_ptr, st))
+        torch.cuda.synchronize()
+        n_parts = int(L.lib.pqlk_dpg_fused_loss_parts())
+        loss_new = float(parts[:n_parts].double().sum()) * (-1.0 / B)
+        np.testing.assert_allclose(loss_new, float(ring[0]), rtol=2e-6, atol=1e-7, err_msg=case)
+        scale = float(dz_ref.abs().max())
+        assert scale > 0
+        torch.testing.assert_close(dz[0, :, :A], dz_ref[0, :, :A], rtol=2e-5, atol=1e-9 + 2e-6 * scale, msg=case)
+        assert torch.all(dz[0, :, A:] == 0)
+        assert torch.isfinite(g_new).all()
+        torch.testing.assert_close(g_new, g_ref, rtol=2e-5, atol=1e-9 + 2e-6 * float(g_ref.abs().max()), msg=case)
+        mn = ws_c2.view(torch.int32)[int(L.lib.pqlk_dpg_fused_mn_offset(C.byref(cl.desc), B)):][:4].tolist()
+        own = owner.cpu().numpy()
+        assert mn[0] == int((own & 1).sum()) and mn[1] == int(((own >> 1) & 1).sum()) and mn[2] % 128 == 0 and mn[3] % 128 == 0
+
+
 _GEMM_LOOP_SCRIPT = r"""
 import ctypes as C, hashlib, sys
 sys.path.insert(0, {tests!r}); sys.path.insert(0, {root!r})

@@ -41,9 +41,15 @@ def _fill(O, A, rows, seed):
 
 
 def _check_module(module, g, prefix, rtol=5e-5, atol=5e-7):
+    """Fingerprint [sum, l2, probes...] of every parameter tensor against the golden trace.  The probes and the l2 norm are held to
+    rtol / atol.  The plain SUM of a weight matrix is a cancelling statistic (|sum| ~ 0.1 for an l2 of ~9 over 131 072 weights), and
+    AdamW turns the rounding noise of near-zero gradients into updates of up to ~0.1 lr (g ~ eps = 1e-8: lr g / (|g| + eps)), so it is
+    held to an absolute bar scaled by the tensor's l2 norm instead: 2e-6 l2 (a 7e-6 drift of that sum after three steps, probes
+    intact, is what the DDPG trace shows between torch's summation order and the MFMA k-order)."""
     for key, view in module.named_views():
-        np.testing.assert_allclose(dd.summarize(view.cpu().numpy()), g[f"{prefix}{key}"], rtol=rtol, atol=atol,
-                                   err_msg=prefix + key)
+        got, want = dd.summarize(view.cpu().numpy()), g[f"{prefix}{key}"]
+        np.testing.assert_allclose(got[1:], want[1:], rtol=rtol, atol=atol, err_msg=prefix + key)
+        np.testing.assert_allclose(got[0], want[0], rtol=rtol, atol=atol + 2e-6 * float(want[1]), err_msg=prefix + key + " (sum)")
 
 
 @pytest.mark.parametrize("streams", [False, True])

@@ -1,7 +1,7 @@
 set -e
 mkdir -p gpurun_out/r4b
 export TMPDIR=/tmp
-python -m pytest tests -m gpu -x -q -k "ddpg or target_actor or obs_ring" > gpurun_out/r4b/tests.log 2>&1 || { tail -30 gpurun_out/r4b/tests.log; exit 1; }
+python -m pytest tests/test_handoff_gpu.py -m gpu -x -q > gpurun_out/r4b/tests.log 2>&1 || { tail -40 gpurun_out/r4b/tests.log; exit 1; }
 tail -2 gpurun_out/r4b/tests.log
 for F in 3 7 11 15; do
   PQL_GATHER_FLAGS=$F python bench.py --no-cpu-baseline --repeat 1 > gpurun_out/r4b/bench_f$F.json 2> gpurun_out/r4b/bench_f$F.err
