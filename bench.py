@@ -136,11 +136,9 @@ def build_system(args, rank, world, device, pg, learner_device=None):
     v = PQLVLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=groups["v"])
     p = PQLPLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=groups["p"])
     if pg is not None:   # replicated parameters: every rank starts from rank 0's weights
+        from pql_amd.utils.dp import broadcast_from_rank0
         for t in (v.critic.arena.data, p.actor.arena.data):
-            if torch.distributed.get_backend(pg) == "gloo":
-                h = t.cpu(); torch.distributed.broadcast(h, src=0, group=pg); t.copy_(h)
-            else:
-                torch.distributed.broadcast(t, src=0, group=pg)
+            broadcast_from_rank0(t, pg)
         v.critic_target.arena.data.copy_(v.critic.arena.data)
         actor.obs_rms.pg = groups["rms"]
     return cfg, env, actor, v, p

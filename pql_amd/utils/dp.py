@@ -56,6 +56,41 @@ def shard(num_envs, memory_size, batch_size, world, rank, scaling="strong") -> S
     return Shard(world, rank, "strong", num_envs // world, per_mem, batch_size // world, num_envs, rank * (num_envs // world))
 
 
+def init_data_parallel(backend="nccl", share_gpu=False, local_rank=0):
+    """torch.distributed set-up of one data-parallel rank; returns (process group, device index).  backend "nccl" = RCCL over xGMI,
+    one GPU per rank (production).  "gloo" = the rehearsal backend: collectives are staged through host memory, so the ranks may
+    share ONE card (`share_gpu`, every rank on cuda:0) -- RCCL refuses two ranks on one device -- which is how the entry point's
+    data-parallel branch is exercised on a one-GPU box."""
+    import torch
+    import torch.distributed as dist
+    backend = str(backend)
+    if backend not in ("nccl", "gloo"):
+        raise ValueError(f"algo.dp_backend must be 'nccl' (RCCL) or 'gloo' (rehearsal), got {backend!r}")
+    if share_gpu and backend == "nccl":
+        raise ValueError("algo.dp_share_gpu=True puts every rank on cuda:0, which RCCL refuses (duplicate device): set algo.dp_backend=gloo")
+    index = 0 if share_gpu else int(local_rank)
+    if index >= torch.cuda.device_count():
+        raise RuntimeError(f"rank-local GPU {index} does not exist ({torch.cuda.device_count()} visible); "
+                           "algo.dp_backend=gloo algo.dp_share_gpu=True rehearses on one card")
+    torch.cuda.set_device(index)
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{index}"))
+    else:
+        dist.init_process_group("gloo")
+    return dist.group.WORLD, index
+
+
+def broadcast_from_rank0(t, pg):
+    """In-place broadcast of rank 0's tensor (replicated parameters start equal); gloo: staged through the host."""
+    import torch.distributed as dist
+    if dist.get_backend(pg) == "gloo" and t.is_cuda:
+        h = t.cpu()
+        dist.broadcast(h, src=0, group=pg)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=0, group=pg)
+
+
 def component_groups(pg, names=("v", "p", "rms")):
     """One communicator per collective-issuing component.  Every rank must call this at the same point (new_group is itself
     collective).  pg None -> {name: None}."""

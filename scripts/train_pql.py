@@ -16,7 +16,9 @@ the design ratios 1 : critic_sample_ratio : critic_sample_ratio / critic_actor_r
       pql_amd.utils.ratio_control.RatioController) tells whoever is too fast how long to sleep per unit.
 
 With torchrun (WORLD_SIZE > 1) the env axis and the replay shard data-parallel and gradients are all-reduced over
-RCCL (fixed-ratio loop only: free-running ranks would issue their collectives out of step).  `algo.dp_global=True`
+RCCL (fixed-ratio loop only: free-running ranks would issue their collectives out of step); `algo.dp_backend=gloo
+algo.dp_share_gpu=True` runs the same branch with host-staged collectives and every rank on cuda:0 (rehearsal on a one-GPU box:
+RCCL refuses two ranks on one device).  `algo.dp_global=True`
 (default) reads num_envs / algo.memory_size / algo.batch_size as the JOB's sizes and gives every rank 1/G of each, so
 BASELINE configs[3] (`num_envs=16384` on 8 GPUs) runs as written; `algo.dp_global=False` reads them per rank (weak scaling).
 V-learner, P-learner and the running statistics each get their own RCCL communicator (pql_amd/utils/dp.py).
@@ -38,7 +40,7 @@ from pql_amd.algo.pql_v_learner import PQLVLearner, asyn_v_learner  # noqa: E402
 from pql_amd.envs.synthetic import create_task_env  # noqa: E402
 from pql_amd.utils.cfg import load_cfg  # noqa: E402
 from pql_amd.utils.common import capture_keyboard_interrupt, preprocess_cfg, set_random_seed  # noqa: E402
-from pql_amd.utils.dp import component_groups, shard  # noqa: E402
+from pql_amd.utils.dp import broadcast_from_rank0, component_groups, init_data_parallel, shard  # noqa: E402
 from pql_amd.utils.evaluator import Evaluator  # noqa: E402
 from pql_amd.utils.logger import MetricLogger  # noqa: E402
 from pql_amd.utils.ratio_control import RatioController  # noqa: E402
@@ -49,7 +51,7 @@ def agree_to_stop(stop, pg, device):
     wall-clock criterion can differ between ranks -- take rank 0's verdict."""
     if pg is None:
         return stop
-    flag = torch.tensor([1.0 if stop else 0.0], device=device)
+    flag = torch.tensor([1.0 if stop else 0.0], device=device if torch.distributed.get_backend(pg) == "nccl" else "cpu")
     torch.distributed.broadcast(flag, src=0, group=pg)
     return bool(flag.item())
 
@@ -60,9 +62,8 @@ def main(cfg):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     pg = None
     if world > 1:
-        torch.cuda.set_device(local)
-        torch.distributed.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-        pg = torch.distributed.group.WORLD
+        # algo.dp_backend=nccl (RCCL, one GPU per rank); gloo + algo.dp_share_gpu=True rehearses this branch on ONE card
+        pg, local = init_data_parallel(cfg.algo.get("dp_backend", "nccl"), bool(cfg.algo.get("dp_share_gpu", False)), local)
         cfg.device = cfg.sim_device = cfg.rl_device = f"cuda:{local}"
         cfg.algo.v_learner_gpu = cfg.algo.p_learner_gpu = local
         cfg.algo.num_gpus = 1
@@ -92,7 +93,7 @@ def main(cfg):
     p_learner = PQLPLearner(env.observation_space.shape, env.action_space.shape[0], cfg, process_group=groups["p"])
     if world > 1:
         for t in (v_learner.critic.arena.data, p_learner.actor.arena.data):
-            torch.distributed.broadcast(t, src=0, group=pg)
+            broadcast_from_rank0(t, pg)
         v_learner.critic_target.arena.data.copy_(v_learner.critic.arena.data)
         if pql_actor.obs_rms is not None:
             pql_actor.obs_rms.pg = groups["rms"]
@@ -173,12 +174,20 @@ def main(cfg):
             logger.log(evaluator.parent.recv(), global_steps)
         evaluator.close()
     torch.cuda.synchronize()
+    import hashlib
+    sha = lambda t: hashlib.sha256(t.detach().cpu().numpy().tobytes()).hexdigest()[:16]   # noqa: E731  (replicas must stay bit-equal)
+    fingerprints = dict(critic_sha=sha(v_learner.critic.arena.data), critic_target_sha=sha(v_learner.critic_target.arena.data),
+                        actor_sha=sha(p_learner.actor.arena.data))
     if world > 1:
+        torch.distributed.barrier(group=pg)
         torch.distributed.destroy_process_group()
-    return dict(global_steps=global_steps, critic_updates=v_learner.update_count, actor_updates=p_learner.update_count,
+    return dict(rank=rank, world=world, **fingerprints, global_steps=global_steps, critic_updates=v_learner.update_count, actor_updates=p_learner.update_count,
                 critic_loss=v_learner.loss_mean(), actor_loss=p_learner.loss_mean(), rollout_iterations=iter_t + 1, waits=(None if ctl is None else (ctl.sim_wait_time, ctl.critic_wait_time,
                                                                                  ctl.actor_wait_time)))
 
 
 if __name__ == "__main__":
-    print(main(load_cfg(sys.argv[1:])))
+    import json
+    result = main(load_cfg(sys.argv[1:]))
+    sys.stdout.flush()
+    os.write(1, ("TRAIN_PQL_RESULT " + json.dumps(result) + "\n").encode())   # one write: the ranks of a torchrun job share the pipe

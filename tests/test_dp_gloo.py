@@ -37,12 +37,16 @@ def _worker(rank, world, port, fn, ret):
         dist.destroy_process_group()
 
 
-def run2(fn):
-    world, port = 2, _free_port()
+def run_world(fn, world):
+    port = _free_port()
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, fn, ret), nprocs=world, join=True)
     return [ret[r] for r in range(world)]
+
+
+def run2(fn):
+    return run_world(fn, 2)
 
 
 # --------------------------------------------------------------------------- gradient all-reduce == full batch
@@ -256,3 +260,98 @@ def _buckets(rank, world):
 def test_gradient_buckets_tile_the_arena_and_sum_like_one_all_reduce():
     a, b = run2(_buckets)
     assert a[0] and b[0] and a[1] == b[1] and a[1] > 0
+
+
+# --------------------------------------------------------------------------- BASELINE configs[3] as written: EIGHT ranks
+CFG3 = dict(num_envs=16384, memory_size=5_000_000, batch=8192, O=211, A=20, atoms=51, hidden=[512, 512, 256])
+
+
+def _cfg3_rank(rank, world):
+    """One of the 8 ranks of configs[3] (PQL-D, 16384 ShadowHand-shape envs, replay 5 M, batch 8192, env-sharded + gradient
+    all-reduce): the host-side and collective logic of the data-parallel path at the sizes the config names -- shard arithmetic,
+    the rank's env shard, the merged running statistics, the global noise index, the gradient buckets of the C51 twin critic."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from pql_amd.envs.synthetic import SyntheticVecEnv
+    from pql_amd.models.mlp import ArenaLayout
+    from pql_amd.utils.dp import BucketAllReduce, bucket_views, component_groups, layer_buckets, shard
+    from pql_amd.utils.noise import add_mixed_normal_noise
+    from pql_amd.utils.torch_util import RunningMeanStd
+    c = CFG3
+    sh = shard(c["num_envs"], c["memory_size"], c["batch"], world, rank, "strong")
+    out = dict(shard=(sh.num_envs, sh.memory_size, sh.batch_size, sh.total_envs, sh.env_offset, sh.global_batch))
+    groups = component_groups(dist.group.WORLD)              # three communicators, as scripts/train_pql.py makes them
+    # the rank's env shard: first observations + two steps (checked against slices of the 16384-env job by the parent)
+    env = SyntheticVecEnv(sh.num_envs, c["O"], c["A"], device="cpu", seed=42, env_offset=sh.env_offset)
+    obs = env.reset()
+    out["obs_sum"] = float(obs.double().sum()); out["obs_head"] = obs[:2, :3].numpy().copy()
+    # running statistics: every rank folds in EVERY rank's batch moments in rank order (torch_util.py:91-103 per batch)
+    rms = RunningMeanStd(shape=(c["O"],), device="cpu")
+    rms.pg = groups["rms"]
+    x = obs
+    for step in range(2):
+        rms.merge_batch(x.mean(0), x.var(0), x.shape[0])
+        x, _, _, _ = env.step(T(dd.uniform((sh.num_envs, c["A"]), 900 + step)))
+    out["rms"] = np.concatenate([rms.mean.numpy(), rms.var.numpy(), [rms.count]])
+    # exploration noise: sigma of GLOBAL env e = linspace(std_min, std_max, 16384)[e]  (noise.py:30-41)
+    torch.manual_seed(5)
+    noise = add_mixed_normal_noise(torch.zeros(sh.num_envs, c["A"]), 0.8, 0.05, env_offset=sh.env_offset, total_envs=sh.total_envs)
+    torch.manual_seed(5)
+    draw = torch.empty(sh.num_envs, c["A"]).normal_()
+    std = torch.linspace(0.05, 0.8, sh.total_envs)[sh.env_offset: sh.env_offset + sh.num_envs]
+    out["noise_ok"] = bool(torch.allclose(noise, draw * std.unsqueeze(1)))
+    # the C51 twin critic's gradient arena in per-layer buckets on the V-learner's communicator == one all-reduce of the arena
+    lay = ArenaLayout([c["O"] + c["A"], *c["hidden"], c["atoms"]], 2)
+    g = T(dd.uniform((lay.total,), 70 + rank, -1, 1)).clone()
+    whole = g.clone()
+    dist.all_reduce(whole, group=groups["v"])
+    cover = torch.zeros(lay.total, dtype=torch.int32)
+    red = BucketAllReduce(groups["v"])
+    for hi, lo in layer_buckets(lay.n_layers):
+        red.issue(bucket_views(g, lay, hi, lo))
+        for cv in bucket_views(cover, lay, hi, lo):
+            cv += 1
+    red.wait()
+    # every element in exactly one bucket; the bucketed sums are the one-collective sums up to the ORDER the ranks' addends are taken
+    # in (a ring all-reduce starts each chunk at a different rank, and the chunking follows the message size: with more than two
+    # ranks the two forms differ in the last bit of some elements, while every RANK still receives the same bits -- checked below)
+    out["tiling_ok"] = bool((cover == 1).all())
+    out["bucket_err"] = float((g - whole).abs().max() / whole.abs().max())
+    out["grad_fp"] = float(whole.double().abs().sum())
+    out["bucket_fp"] = float(g.double().sum())
+    # per-rank batch means average to the job's batch mean (equal shards): all-reduce(sum) / G of a per-rank scalar
+    m = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(m, group=groups["p"])
+    out["mean_of_means"] = float(m / world)
+    return out
+
+
+def test_configs3_split_as_written_on_eight_ranks():
+    """BASELINE configs[3] ("16384 envs ... 8 x MI355X env-sharded + RCCL grad all-reduce") split over EIGHT gloo ranks exactly as
+    scripts/train_pql.py / bench.py --scaling strong would split it: 2048 envs / 625 000 rows / batch 1024 per rank.  All 8 ranks
+    must hold identical running statistics, equal to the single-process merge in rank order; the shards are slices of the job's env
+    axis; the noise scale follows the global env index; the per-layer gradient buckets tile the C51 critic's arena and sum like one
+    all-reduce.  (The reference has no data parallelism: scripts/train_pql.py:41-70 places three Ray actors on GPUs by function.)"""
+    from oracle import pql_ref_cpu as ref
+    from pql_amd.envs.synthetic import SyntheticVecEnv
+    world, c = 8, CFG3
+    outs = run_world(_cfg3_rank, world)
+    assert [o["shard"] for o in outs] == [(2048, 625_000, 1024, 16384, 2048 * r, 8192) for r in range(world)]
+    for o in outs[1:]:
+        assert np.array_equal(o["rms"], outs[0]["rms"])                       # identical on all 8 ranks, bit for bit
+        assert o["grad_fp"] == outs[0]["grad_fp"] and o["bucket_fp"] == outs[0]["bucket_fp"]   # replicas stay identical either way
+    assert all(o["noise_ok"] and o["tiling_ok"] for o in outs)
+    assert all(o["bucket_err"] < 1e-6 for o in outs)
+    assert all(abs(o["mean_of_means"] - 4.5) < 1e-12 for o in outs)
+    # the job's env in ONE process: shards are slices, and the merged statistics are the rank-order merge of the slices' moments
+    full = SyntheticVecEnv(c["num_envs"], c["O"], c["A"], device="cpu", seed=42)
+    x = full.reset()
+    for r, o in enumerate(outs):
+        sl = x[2048 * r: 2048 * (r + 1)]
+        assert np.array_equal(o["obs_head"], sl[:2, :3].numpy()) and abs(o["obs_sum"] - float(sl.double().sum())) < 1e-6
+    single = ref.RunningMeanStdRef((c["O"],))
+    for step in range(2):
+        for r in range(world):
+            single.update(x[2048 * r: 2048 * (r + 1)])
+        x, _, _, _ = full.step(torch.cat([T(dd.uniform((2048, c["A"]), 900 + step)) for _ in range(world)]))
+    np.testing.assert_allclose(outs[0]["rms"], np.concatenate([single.mean.numpy(), single.var.numpy(), [single.count]]), rtol=2e-6, atol=1e-7)

@@ -421,3 +421,52 @@ def test_published_snapshot_reads_wait_for_the_learner_stream():
         ref.arena.data.fill_(0.25)
         want = ref(x) if cls is TanhMLPPolicy else ref.get_q1(x, torch.ones((4, 2), device=dev))
         torch.testing.assert_close(y, want, rtol=0, atol=0)
+
+
+def _run_train_pql_ranks(world, overrides, port, timeout=600):
+    """`python -m torch.distributed.run --nproc-per-node <world> scripts/train_pql.py ...` as a CHILD process (the ranks initialise the
+    GPU themselves) -> the per-rank result dicts, ordered by rank."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "scripts", "train_pql.py"), *overrides],
+                       env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, (r.stderr[-3000:], r.stdout[-1000:])
+    import re
+    outs = [json.loads(m.group(1)) for m in re.finditer(r"TRAIN_PQL_RESULT (\{.*?\})\s*(?=TRAIN_PQL_RESULT|$)", r.stdout, re.S)]
+    assert len(outs) == world, r.stdout[-2000:]
+    return sorted(outs, key=lambda o: o["rank"])
+
+
+@pytest.mark.parametrize("distl", [False, True])
+def test_train_pql_data_parallel_branch_two_ranks_on_one_card(distl):
+    """scripts/train_pql.py's WORLD_SIZE > 1 branch (train_pql.py: init_data_parallel, shard, component_groups, the rank-0 broadcast of
+    the initial arenas, the merged running statistics, rank-0-only evaluator / logging, the stop agreement and the barrier before
+    destroy_process_group) executed END TO END with two ranks: strong mode (the job's 128 envs / 8000 rows / batch 512 split in
+    two), algo.dp_backend=gloo + algo.dp_share_gpu=True because this box has one card and RCCL refuses two ranks on one device.
+    Both ranks must leave the loop in the same iteration with the same counters, and -- replicated optimiser on all-reduced
+    gradients -- with BIT-EQUAL critic, target and actor arenas."""
+    outs = _run_train_pql_ranks(2, ["task.name=Toy", "num_envs=128", "algo.batch_size=512", "algo.memory_size=8000", "max_step=12000",
+                                    "algo.dp_backend=gloo", "algo.dp_share_gpu=True", f"algo.distl={distl}", "algo.graph=True",
+                                    "algo.eval_freq=20", "algo.log_freq=10"], port=29611 + int(distl))
+    a, b = outs
+    assert (a["rank"], b["rank"], a["world"], b["world"]) == (0, 1, 2, 2)
+    for k in ("global_steps", "critic_updates", "actor_updates", "rollout_iterations", "critic_sha", "critic_target_sha", "actor_sha"):
+        assert a[k] == b[k], (k, a[k], b[k])
+    iters = a["rollout_iterations"]
+    assert a["critic_updates"] == 8 * iters and a["actor_updates"] == 4 * iters and a["global_steps"] >= 12000
+    assert a["global_steps"] == 128 * 32 + iters * 128        # JOB-wide env steps: warm-up (32 steps) + one step of all 128 envs per iteration
+    assert np.isfinite(a["critic_loss"]) and np.isfinite(b["actor_loss"])
+
+
+def test_train_pql_data_parallel_wall_clock_stop_is_agreed():
+    """max_step unset: the stop criterion is wall-clock time, which differs between ranks -- rank 0's verdict is broadcast
+    (agree_to_stop) so that nobody enters an iteration whose collectives the other rank will not join.  Weak mode here."""
+    outs = _run_train_pql_ranks(2, ["task.name=Toy", "num_envs=64", "algo.batch_size=256", "algo.memory_size=4000", "max_time=4",
+                                    "algo.dp_backend=gloo", "algo.dp_share_gpu=True", "algo.dp_global=False", "algo.eval_freq=1000000",
+                                    "algo.log_freq=1000000"], port=29621)
+    a, b = outs
+    assert a["rollout_iterations"] == b["rollout_iterations"] > 3 and a["critic_sha"] == b["critic_sha"] and a["actor_sha"] == b["actor_sha"]
+    assert a["global_steps"] == 2 * (64 * 32 + a["rollout_iterations"] * 64)   # weak: every rank brings its own 64 envs
