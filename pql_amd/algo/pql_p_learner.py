@@ -81,6 +81,9 @@ class PQLPLearner:
         self.gen.manual_seed(int(torch.randint(0, 2 ** 62, (1,)).item()))
         # algo.rng / algo.prefetch_steps: see PQLVLearner.__init__ (here: one randint per step, P-steps of one rollout iteration)
         self._rng_mode = str(_cfg_get(algo, "rng", "auto"))
+        if self._rng_mode != "torch":   # see PQLVLearner.__init__
+            with torch.cuda.device(self.device):
+                R.verified(self.device)
         ratio = max(1, int(_cfg_get(algo, "critic_sample_ratio", 8)) // max(1, int(_cfg_get(algo, "critic_actor_ratio", 2))))
         self._depth = max(1, int(_cfg_get(algo, "prefetch_steps_p", ratio)))
         self._ahead = None
@@ -117,6 +120,21 @@ class PQLPLearner:
     def _drop_ahead(self):
         if self._ahead is not None:
             self._ahead.invalidate()
+
+    def _data_stamp(self):
+        """See PQLVLearner._data_stamp: ring contents, randint bound, identity of the statistics."""
+        nt = self.normalize_tuple
+        return (self.ring.version, self.cur_capacity, None if nt is None else (id(nt[0]), id(nt[1]), float(nt[2])))
+
+    def _norm_key(self):
+        """Part of every graph key: a captured gather has the ADDRESSES of the statistics baked in (update() keeps them stable by
+        copying into resident buffers; a tuple assigned from outside brings new ones and must re-capture)."""
+        nt = self.normalize_tuple
+        return None if nt is None else (nt[0].data_ptr(), nt[1].data_ptr(), float(nt[2]))
+
+    def _check_ahead(self):
+        if self._ahead is not None and self._ahead.valid and getattr(self, "_ahead_stamp", None) != self._data_stamp():
+            self._drop_ahead()
 
     @property
     def rng(self):
@@ -200,6 +218,7 @@ class PQLPLearner:
         """The next K steps' indices (torch's numbers, one launch) and ONE gather of their K x B observation rows."""
         self._ahead.refill(self.cur_capacity)
         self._gather(ws, self._ahead.idx, ws["K"] * ws["B"], ws["x_sa_all"], ws["x_obs_all"])
+        self._ahead_stamp = self._data_stamp()
 
     def _step_kernels(self, ws, idx, upto_backward=False, tiles=None):
         algo, dev, B = self.cfg.algo, self.device, ws["B"]
@@ -299,11 +318,12 @@ class PQLPLearner:
                 H.release(lease, st)
                 self._step_kernels(ws, ws["idx"])
             elif self._ahead is not None and self.cur_capacity < (1 << 28):   # see PQLVLearner.learn
+                self._check_ahead()
                 if self._ahead.valid == 0:
                     self._prefetch(ws)
                 slot = self._ahead.take()
                 if self.use_graph:
-                    key = (B, 0, id(self.critic), self.normalize_tuple is None)
+                    key = (B, 0, id(self.critic), self._norm_key())
                     if self._graph_key != key:
                         self._slot_graphs, self._run_graph, self._graph, self._graph_post, self._graph_key = {}, None, None, None, key
                     if slot not in self._slot_graphs:
@@ -316,7 +336,7 @@ class PQLPLearner:
                 else:
                     self._step_kernels(ws, None, tiles=ws["slots"][slot])
             elif self.use_graph:
-                key = (B, self.cur_capacity if self._graph_rng else 0, id(self.critic), self.normalize_tuple is None)
+                key = (B, self.cur_capacity if self._graph_rng else 0, id(self.critic), self._norm_key())
                 if self._graph is None or self._graph_key != key:
                     with H.CAPTURE_LOCK:
                         self._capture(ws, key)
@@ -341,12 +361,13 @@ class PQLPLearner:
         B = int(self.cfg.algo.batch_size)
         with self._lock, torch.cuda.device(self.device), self._on_stream():
             ws = self._workspace(B)
+            self._check_ahead()
             if (self.use_graph and self._run_graphs and self._ahead is not None and n == ws["K"] and n > 1 and self._ahead.valid in (0, n)
                     and (self._ahead.valid == 0 or self._ahead.pos == 0) and self.cur_capacity < (1 << 28)
                     and (not self.dp or graph_collective_enabled(self.pg))):
                 if self._ahead.valid == 0:
                     self._prefetch(ws)
-                key = (B, 0, id(self.critic), self.normalize_tuple is None)
+                key = (B, 0, id(self.critic), self._norm_key())
                 if self._graph_key != key:
                     self._slot_graphs, self._run_graph, self._graph, self._graph_post, self._graph_key = {}, None, None, None, key
                 if self._run_graph is None:
@@ -393,7 +414,7 @@ class PQLPLearner:
         with self._lock, torch.cuda.device(self.device), self._on_stream():
             ws = self._workspace(int(self.cfg.algo.batch_size))
             if self.use_graph and self._ahead is not None and 0 < self.cur_capacity < (1 << 28):
-                key = (ws["B"], 0, id(self.critic), self.normalize_tuple is None)
+                key = (ws["B"], 0, id(self.critic), self._norm_key())
                 if self._graph_key != key:
                     self._slot_graphs, self._run_graph, self._graph, self._graph_post, self._graph_key = {}, None, None, None, key
                 off = self.gen.get_offset()
@@ -408,7 +429,7 @@ class PQLPLearner:
                 self._drop_ahead()
                 self.gen.set_offset(off)
             elif self.use_graph:
-                key = (ws["B"], self.cur_capacity if self._graph_rng else 0, id(self.critic), self.normalize_tuple is None)
+                key = (ws["B"], self.cur_capacity if self._graph_rng else 0, id(self.critic), self._norm_key())
                 if self._graph is None or self._graph_key != key:
                     with H.CAPTURE_LOCK:
                         self._capture(ws, key)

@@ -299,6 +299,9 @@ class PQLVLearner:
         # (pql_amd/utils/rng.py), else "torch"; "torch" = one randint + one normal_ ATen launch in front of every step (round 2);
         # "philox" = as auto, but refuse to run when the check fails.
         self._rng_mode = str(_cfg_get(algo, "rng", "auto"))
+        if self._rng_mode != "torch":   # the on-device check runs HERE, once, under a lock (not lazily inside the first learn(),
+            with torch.cuda.device(self.device):   # which free-running learners reach from two threads at the same time)
+                R.verified(self.device)
         self._depth = max(1, int(_cfg_get(algo, "prefetch_steps", _cfg_get(algo, "critic_sample_ratio", 8))))
         self._ahead = None
         self._ws = None
@@ -332,6 +335,25 @@ class PQLVLearner:
         changed): the next step prepares them again at the generator's current offset."""
         if self._ahead is not None:
             self._ahead.invalidate()
+
+    def _data_stamp(self):
+        """What the tiles gathered ahead depend on besides the draws: the ring's contents (insert counter), the randint bound and
+        the identity of the normalisation statistics.  `update()` drops the tiles itself; this catches every OTHER way the data can
+        change under a learner that has steps prepared -- `memory.add_to_buffer(...)` called directly, `normalize_tuple` or
+        `memory.cur_capacity` assigned from outside (tools/gen_golden-style drivers, tests) -- which would otherwise train up to
+        K - 1 steps on stale rows, stale statistics or a stale bound without any error."""
+        nt = self.normalize_tuple
+        return (self.memory.ring.version, self.memory.cur_capacity, None if nt is None else (id(nt[0]), id(nt[1]), float(nt[2])))
+
+    def _norm_key(self):
+        """Part of every graph key: a captured gather has the ADDRESSES of the statistics baked in (update() keeps them stable by
+        copying into resident buffers; a tuple assigned from outside brings new ones and must re-capture)."""
+        nt = self.normalize_tuple
+        return None if nt is None else (nt[0].data_ptr(), nt[1].data_ptr(), float(nt[2]))
+
+    def _check_ahead(self):
+        if self._ahead is not None and self._ahead.valid and getattr(self, "_ahead_stamp", None) != self._data_stamp():
+            self._drop_ahead()
 
     @property
     def rng(self):
@@ -444,6 +466,7 @@ class PQLVLearner:
         K, B = ws["K"], ws["B"]
         self._ahead.refill(self.memory.cur_capacity)
         self._gather(ws, self._ahead.idx, K * B, ws["x_sa_all"], ws["xn_sa_all"], ws["rew_all"], ws["done_all"])
+        self._ahead_stamp = self._data_stamp()
 
     def _step_kernels(self, ws, idx, draw, upto_backward=False, tiles=None, part=None):
         """The launch sequence of one critic gradient step; everything asynchronous on the current stream.
@@ -590,11 +613,12 @@ class PQLVLearner:
             elif self._ahead is not None and self.memory.cur_capacity < (1 << 28):
                 # draws + input tiles of the next K steps come from one launch pair (`_prefetch`), the step itself has no RNG
                 # and no gather launch left; one hipGraph per slot (the tiles' addresses are baked in)
+                self._check_ahead()
                 if self._ahead.valid == 0:
                     self._prefetch(ws)
                 slot = self._ahead.take()
                 if self.use_graph:
-                    key = (B, 0, id(self.actor), self.normalize_tuple is None)
+                    key = (B, 0, id(self.actor), self._norm_key())
                     if self._graph_key != key:
                         self._slot_graphs, self._run_graph, self._graph, self._graph_post, self._graph_key = {}, None, None, None, key
                     if slot not in self._slot_graphs:
@@ -604,7 +628,7 @@ class PQLVLearner:
                 else:
                     self._step_kernels(ws, None, self._ahead.normal[slot], tiles=ws["slots"][slot])
             elif self.use_graph:
-                key = (B, self.memory.cur_capacity if self._graph_rng else 0, id(self.actor), self.normalize_tuple is None)
+                key = (B, self.memory.cur_capacity if self._graph_rng else 0, id(self.actor), self._norm_key())
                 if self._graph is None or self._graph_key != key:
                     with H.CAPTURE_LOCK:
                         self._capture(ws, key)
@@ -636,10 +660,11 @@ class PQLVLearner:
         B = int(self.cfg.algo.batch_size)
         with self._lock, torch.cuda.device(self.device), self._on_stream():
             ws = self._workspace(B)
+            self._check_ahead()
             if self._run_in_one_graph(ws, n):
                 if self._ahead.valid == 0:
                     self._prefetch(ws)
-                key = (B, 0, id(self.actor), self.normalize_tuple is None)
+                key = (B, 0, id(self.actor), self._norm_key())
                 if self._graph_key != key:
                     self._slot_graphs, self._run_graph, self._graph, self._graph_post, self._graph_key = {}, None, None, None, key
                 if self._run_graph is None:
@@ -696,7 +721,7 @@ class PQLVLearner:
         with self._lock, torch.cuda.device(self.device), self._on_stream():
             ws = self._workspace(int(self.cfg.algo.batch_size))
             if self.use_graph and self._ahead is not None and 0 < self.memory.cur_capacity < (1 << 28):
-                key = (ws["B"], 0, id(self.actor), self.normalize_tuple is None)
+                key = (ws["B"], 0, id(self.actor), self._norm_key())
                 if self._graph_key != key:
                     self._slot_graphs, self._run_graph, self._graph, self._graph_post, self._graph_key = {}, None, None, None, key
                 off = self.gen.get_offset()
@@ -711,7 +736,7 @@ class PQLVLearner:
                 self._drop_ahead()
                 self.gen.set_offset(off)
             elif self.use_graph:
-                key = (ws["B"], self.memory.cur_capacity if self._graph_rng else 0, id(self.actor), self.normalize_tuple is None)
+                key = (ws["B"], self.memory.cur_capacity if self._graph_rng else 0, id(self.actor), self._norm_key())
                 if self._graph is None or self._graph_key != key:
                     with H.CAPTURE_LOCK:
                         self._capture(ws, key)

@@ -58,8 +58,10 @@ class RecordRing:
         o4 = (self.O + 3) & ~3
         self.off_nobs, self.off_act = o4, 2 * o4
         self.off_rd = 2 * o4 + ((max(self.A, 0) + 3) & ~3)
+        self.version = 0   # bumped by every insert: the learners' draws-ahead tiles are stamped with it (stale tiles are re-gathered)
 
     def insert_segments(self, segs, obs, act=None, rew=None, nobs=None, done=None):
+        self.version += 1
         with torch.cuda.device(self.device):
             st = L.stream(self.device)
             for dst, src, n in segs:

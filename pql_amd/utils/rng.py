@@ -16,11 +16,14 @@ rocRAND build that generates differently simply keeps the ATen launches (`algo.r
 """
 from __future__ import annotations
 
+import threading
+
 import torch
 
 from pql_amd import _lib as L
 
 _VERIFIED = {}   # device index -> contract flag (0 / 1), or None when torch's kernels could not be reproduced
+_VERIFY_LOCK = threading.Lock()   # the learners call verified() from their constructors; free-running ones live in threads
 
 
 def philox_increment(numel: int) -> int:
@@ -40,8 +43,15 @@ def verified(device):
     """Contract flag under which pqlk_philox_draws reproduces torch's randint / normal_ bit for bit on `device`, else None."""
     device = torch.device(device)
     key = device.index if device.index is not None else torch.cuda.current_device()
-    if key in _VERIFIED:
+    with _VERIFY_LOCK:
+        if key not in _VERIFIED:
+            _VERIFIED[key] = _verify(device)
         return _VERIFIED[key]
+
+
+def _verify(device):
+    """Only a VALUE mismatch (another torch / rocRAND build that generates differently) or a torch without Generator.set_offset
+    means "cannot be reproduced" -> None -> the learners keep the ATen launches.  A failing launch is an error and surfaces."""
     result = None
     try:
         for contract in (1, 0):
@@ -68,9 +78,8 @@ def verified(device):
             if ok:
                 result = contract
                 break
-    except (RuntimeError, AttributeError):
+    except AttributeError:   # torch.Generator without get_offset / set_offset
         result = None
-    _VERIFIED[key] = result
     return result
 
 

@@ -43,6 +43,7 @@ from pql_amd.utils.common import capture_keyboard_interrupt, preprocess_cfg, set
 from pql_amd.utils.dp import broadcast_from_rank0, component_groups, init_data_parallel, shard  # noqa: E402
 from pql_amd.utils.evaluator import Evaluator  # noqa: E402
 from pql_amd.utils.logger import MetricLogger  # noqa: E402
+from pql_amd.utils import rng as R  # noqa: E402
 from pql_amd.utils.ratio_control import RatioController  # noqa: E402
 
 
@@ -67,6 +68,12 @@ def main(cfg):
         cfg.device = cfg.sim_device = cfg.rl_device = f"cuda:{local}"
         cfg.algo.v_learner_gpu = cfg.algo.p_learner_gpu = local
         cfg.algo.num_gpus = 1
+    if bool(cfg.algo.get("async_learners", False)):
+        # free-running learners meet a hand-off after an arbitrary number of steps, and every hand-off discards what was gathered
+        # ahead (~100 MB at cfg #2 with 8 steps ahead): two steps ahead keep the launch-count benefit without that waste
+        for key in ("prefetch_steps", "prefetch_steps_p"):
+            if cfg.algo.get(key) is None:
+                cfg.algo[key] = 2
     sh = shard(cfg.num_envs, cfg.algo.memory_size, cfg.algo.batch_size, world, rank,
                "strong" if bool(cfg.algo.get("dp_global", True)) else "weak")
     cfg.num_envs, cfg.algo.memory_size, cfg.algo.batch_size = sh.num_envs, sh.memory_size, sh.batch_size
@@ -97,6 +104,10 @@ def main(cfg):
         v_learner.critic_target.arena.data.copy_(v_learner.critic.arena.data)
         if pql_actor.obs_rms is not None:
             pql_actor.obs_rms.pg = groups["rms"]
+    if rank == 0:   # which source the learners' draws will come from (algo.rng; decided by the on-device check of pql_amd/utils/rng.py)
+        want = "torch" if str(cfg.algo.get("rng", "auto")) == "torch" or bool(cfg.algo.get("graph_rng", False)) else (
+            "philox (one launch per run of steps, torch's own numbers)" if R.verified(v_dev) is not None else "torch (the philox check failed on this device)")
+        print(f"[train_pql] learner draws: {want}", file=sys.stderr)
     critic, critic_update_times, critic_loss = v_learner.start()
     actor, actor_update_times, actor_loss = p_learner.start()
     pql_actor.set_actor(actor)

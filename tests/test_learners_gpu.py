@@ -471,6 +471,48 @@ def test_draws_ahead_and_batched_gather_equal_the_per_step_torch_draws(dev, grap
     assert v.update_count == 16 and p.update_count == 7   # (1 + 4 + 2 P-steps)
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_draws_ahead_tiles_follow_data_changed_behind_the_learners_back(dev, graph):
+    """The tiles gathered ahead (algo.rng=auto) must not outlive the data they were gathered from when that data changes WITHOUT an
+    `update()` call: rows inserted straight through `memory.add_to_buffer` (the ring's insert counter and the randint bound move)
+    and `normalize_tuple` assigned from outside -- both legal on the reference's objects (pql_v_learner.py:117-122 does nothing
+    else).  With the same seeds the learner must then do exactly what the per-step learner (algo.rng=torch, no tiles ahead) does:
+    bit-identical parameters, loss rings, sample indices and generator offsets."""
+    from pql_amd.algo.pql_v_learner import PQLVLearner
+    from pql_amd.models.mlp import TanhMLPPolicy
+    O, A, B, cap = 8, 2, 256, 3000
+    actor = TanhMLPPolicy((O,), A).to(dev); actor.load_state_dict(_sd(dd.mlp_state(O, A, 11)))
+    outs = []
+    for mode in ("torch", "auto"):
+        cfg = make_cfg(False, B=B, memory=cap, graph=graph)
+        cfg.algo.rng = mode
+        v = PQLVLearner((O,), A, cfg)
+        v.critic.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 21))); v.critic_target.arena.data.copy_(v.critic.arena.data)
+        v.use_private_rng(1234)
+        norm = (T(dd.uniform((O,), 6, -0.5, 0.5)).to(dev), T(dd.uniform((O,), 7, 0.5, 2.0)).to(dev), 1e-4)
+        norm2 = (T(dd.uniform((O,), 16, -0.5, 0.5)).to(dev), T(dd.uniform((O,), 17, 0.5, 2.0)).to(dev), 1e-4)
+        v.update(actor, tuple(t.to(dev) for t in _fill(O, A, 700, 50)), norm, 0)
+        idxs = []
+
+        def steps(n):
+            for _ in range(n):
+                v.learn()
+                idxs.append(v._ahead.idx[(v._ahead.pos - 1)].clone() if v._ahead is not None else v._ws["idx"].clone())
+        steps(3)                                                               # 5 more steps are prepared ahead (auto)
+        v.memory.add_to_buffer(tuple(t.to(dev) for t in _fill(O, A, 500, 60)))   # new rows + a larger randint bound
+        steps(2)
+        v.normalize_tuple = norm2                                              # new statistics
+        steps(4)
+        v.learn_many(8)                                                        # a whole run, nothing stale left
+        torch.cuda.synchronize()
+        assert v.rng == ("philox" if mode == "auto" else "torch")
+        outs.append((v.critic.arena.data.clone(), v.critic_target.arena.data.clone(), v.opt.m.clone(), v.loss_ring.clone(), torch.stack(idxs),
+                     v.gen.get_offset()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+    assert int(outs[0][4][3:].max()) >= 700      # steps after the direct insert really sampled the new rows
+
+
 def test_graph_replay_matches_eager(dev):
     """hipGraph-captured learn() is the same launch sequence: with equal seeds it must reproduce the eager
     parameters bit for bit (same kernels, same order, same RNG offsets)."""
@@ -659,6 +701,24 @@ def _dp_rank(rank, world, port, ret):
                 torch.cuda.synchronize()
                 outs["graph"] = v.critic.arena.data.cpu().numpy()
                 outs["steps"] = v.opt.step.item()
+                # ... and the way the fixed-ratio loop issues them: learn_many(8) for V then learn_many(4) for a P-learner on its own
+                # communicator (scripts/train_pql.py), twice with a hand-off in between -- the slot-graph / run-graph capture
+                # warm-ups and the per-step collectives must stay rank-symmetric or this deadlocks / diverges
+                from pql_amd.algo.pql_p_learner import PQLPLearner
+                from pql_amd.utils.dp import component_groups
+                groups = component_groups(dist.group.WORLD, ("p",))
+                p = PQLPLearner((O,), A, make_cfg(False, B=B // world, graph=True), process_group=groups["p"])
+                p.actor.load_state_dict(_sd(dd.mlp_state(O, A, 11)))
+                p.use_private_rng(77 + rank)
+                for it in range(2):
+                    data = tuple(t.to(dev) for t in _fill(O, A, 100, 900 + 10 * it + rank))   # every rank inserts its OWN rows
+                    critic, _, _ = v.update(p.actor, data, norm, 0)
+                    p.update(critic, data[0], norm, 0)
+                    v.learn_many(8)
+                    p.learn_many(4)
+                torch.cuda.synchronize()
+                outs["many_v"] = v.critic.arena.data.cpu().numpy(); outs["many_p"] = p.actor.arena.data.cpu().numpy()
+                outs["many_counts"] = (v.update_count, p.update_count)
         ret[rank] = outs
     finally:
         dist.destroy_process_group()
@@ -679,6 +739,8 @@ def test_data_parallel_two_ranks_match_single_gpu_step(golden, dev):
         assert ret[r]["steps"] == 3
     # different seeds-per-rank draws differ, but parameters are replicated: identical after the all-reduced steps
     assert np.array_equal(ret[0]["graph"], ret[1]["graph"])
+    assert np.array_equal(ret[0]["many_v"], ret[1]["many_v"]) and np.array_equal(ret[0]["many_p"], ret[1]["many_p"])
+    assert ret[0]["many_counts"] == ret[1]["many_counts"] == (3 + 16, 8)
 
 
 def _dp_bucket_rank(rank, port, ret):
