@@ -72,6 +72,9 @@ def parse():
                          "as one collective after the whole backward, or auto = layer iff PQL_DP_GRAPH_COLLECTIVE=1 (algo.dp_buckets)")
     ap.add_argument("--no-run-graph", action="store_true", help="one hipGraph per learner step instead of one per run of steps between two hand-offs (A/B of algo.run_graph)")
     ap.add_argument("--no-td-forward", action="store_true", help="head backward as its own launch instead of inside the critic's forward (A/B of algo.td_in_forward)")
+    ap.add_argument("--override", action="append", default=[], metavar="KEY=VALUE",
+                    help="extra cfg override in the entry point's syntax (A/B switches: algo.actor_ahead=False, algo.dpg_fused=False ...); "
+                         "recorded in config.overrides")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the roofline / free-running sections after the timed blocks (rocprofv3 kernel-trace runs: the CSV's "
@@ -116,7 +119,7 @@ def build_system(args, rank, world, device, pg, learner_device=None):
           f"algo.v_learner_gpu={(learner_device or device).index}", f"algo.p_learner_gpu={(learner_device or device).index}",
           f"algo.num_gpus={1 if learner_device is None else 2}",
           f"algo.graph={not args.no_graph}", f"algo.graph_rng={bool(getattr(args, 'graph_rng', False))}", f"algo.streams={not args.no_streams}", f"algo.fused={not args.no_fused}", f"sim_device=cuda:{device.index}",
-          f"device=cuda:{device.index}"]
+          f"device=cuda:{device.index}", *getattr(args, "override", [])]
     cfg = load_cfg(ov)
     cfg.algo.hidden_layers = hidden
     cfg.algo.fused_tail = not getattr(args, "no_fused_tail", False)
@@ -254,8 +257,9 @@ def v_section(v):
     def section():
         from pql_amd.models.mlp import mlp_forward_raw
         fused_actor = v.pk_actor is not None and v.pk_actor.tensor is not None
-        mlp_forward_raw(al, v.actor.arena.data, ws["xn_sa"] if fused_actor else ws["xn_obs"], L.ACT_TANH_NOISE, ws["draw"], 0.8, 0.2,
-                        ws["acts_a"], ws["xn_sa"][:, O:], packed=v.pk_actor, stash_all=False)
+        if not ws.get("actor_ahead"):   # (algo.actor_ahead: the K steps' target actions come from one launch at prefetch time: actor_ahead_ms)
+            mlp_forward_raw(al, v.actor.arena.data, ws["xn_sa"] if fused_actor else ws["xn_obs"], L.ACT_TANH_NOISE, ws["draw"], 0.8, 0.2,
+                            ws["acts_a"], ws["xn_sa"][:, O:], packed=v.pk_actor, stash_all=False)
         mlp_forward_raw(cl, v.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"], packed=v.pk_target, stash_all=False)
         if ws.get("td_fwd", 0) > 0:   # the learner's own pair of calls: the Q head's backward rides in the critic's forward launch
             L.check(L.lib.pqlk_mlp_forward_td(C.byref(cl.desc), L.ptr(v.critic.arena.data), L.ptr(v.pk_critic.tensor), L.ptr(ws["x_sa"]), ws["ld_sa"],
@@ -272,11 +276,32 @@ def v_section(v):
     return section
 
 
+def actor_ahead_ms(v, iters=8):
+    """Device time of the ONE target-policy forward that serves the next K V-learner steps (PQLVLearner._prefetch, algo.actor_ahead):
+    K x B rows, tanh + target-policy noise, actions dropped into the K target-critic input tiles.  HIP events around a hipGraph
+    of `iters` launches."""
+    from pql_amd import _lib as L
+    from pql_amd.models.mlp import mlp_forward_raw
+    ws = v._workspace(int(v.cfg.algo.batch_size))
+    K, B, O = ws["K"], ws["B"], v.memory.ring.O
+    xn = ws["xn_sa_all"].view(K * B, ws["ld_sa"])
+    draw = v._ahead.normal.view(K * B, -1)
+
+    def one():
+        mlp_forward_raw(v.actor.layout, v.actor.arena.data, xn, L.ACT_TANH_NOISE, draw, 0.8, 0.2, ws["a_out_all"], xn[:, O:], packed=v.pk_actor,
+                        stash_all=2)
+    with torch.cuda.device(v.device):
+        g = _graph_of(lambda: [one() for _ in range(iters)], v.device)
+        return _replay_ms(g) / iters
+
+
 def gemm_section_ms(v, iters=20):
     """Device time of the forward + backward launches of ONE V-learner step (v_section: the slab sum that closes the backward call is
     the one non-MFMA launch in the interval, ~11 us: the fraction is that much conservative) -- measured with HIP events on the stream
-    they are launched on (torch's current stream)."""
+    they are launched on (torch's current stream).  With algo.actor_ahead the target policy's forward is one launch per K steps: 1 / K
+    of its time is added (actor_ahead_ms)."""
     section = v_section(v)
+    ahead = actor_ahead_ms(v) / v._workspace(int(v.cfg.algo.batch_size))["K"] if v._workspace(int(v.cfg.algo.batch_size)).get("actor_ahead") else 0.0
 
     with torch.cuda.device(v.device):
         for _ in range(3):
@@ -298,7 +323,7 @@ def gemm_section_ms(v, iters=20):
         g.replay()
         e1.record()
         e1.synchronize()
-        return e0.elapsed_time(e1) / iters
+        return e0.elapsed_time(e1) / iters + ahead
 
 
 def dominant_kernel_ms(v, iters=20):
@@ -777,7 +802,7 @@ def main():
                                f"{args.replay} rows resident in HBM, batch {args.batch}, n-step {args.nstep}, "
                                f"{'DistributionalDoubleQ(51)' if args.distl else 'DoubleQ'} MLP {hidden}",
                    "schedule": {"schedule": "1 env-iteration : 4 P-steps : 8 V-steps", "v_only": "v_only", "p_only": "p_only"}[mode],
-                   "graph": not args.no_graph, "rng": v.rng, "burn_in_ms": args.burn_in_ms, "streams": not args.no_streams, "fused_forward": not args.no_fused,
+                   "overrides": list(args.override), "graph": not args.no_graph, "rng": v.rng, "burn_in_ms": args.burn_in_ms, "streams": not args.no_streams, "fused_forward": not args.no_fused,
                    "parallelism": par, "layout": args.layout if args.gpus > 1 else "single", "ranks": world,
                    "per_rank": {"num_envs": args.num_envs, "replay_rows": args.replay, "batch": args.batch},
                    "job": {"num_envs": args.shard.total_envs, "replay_rows": args.replay * world, "batch": args.batch * world},

@@ -187,7 +187,12 @@ int pqlk_mlp_pack(const PqlMlpDesc* d, const float* params, float* packed, pqlk_
  * the block's waves (a reassociation of the same products: ~1e-7 relative to the per-layer result).
  * stash_all = 0 on that path writes only what a forward-only caller needs: the output block, plus the last hidden layer
  * when the output layer is NOT fused; the other activation blocks are left untouched.  Backward needs stash_all = 1.  On the fused path columns [dims[0], ldx) of x are IGNORED (masked to zero while the
- * tile is staged), so x may alias a wider matrix; the per-layer path requires them to be zero. */
+ * tile is staged), so x may alias a wider matrix; the per-layer path requires them to be zero.
+ * stash_all = PQLK_STASH_OUTPUT_ONLY (2): forward-only call where `acts` IS the output block, (n_nets, B, pqlk_ld(out)) floats, and
+ * nothing else is written -- the target policy's actions for the next K learner steps come from ONE launch over K x B rows
+ * (the policy is fixed between two hand-offs, pql_v_learner.py:62-71,117-122) without a K x B activation stash.  Fused hidden stack
+ * + fused output layer only (PQLK_E_UNSUPPORTED otherwise). */
+#define PQLK_STASH_OUTPUT_ONLY 2
 int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const float* packed, int32_t stash_all,
                      const float* x, int64_t ldx, int64_t b,
                      int32_t out_act, const float* draw, float noise_std, float noise_clip,

@@ -343,7 +343,9 @@ class PQLVLearner:
         `memory.cur_capacity` assigned from outside (tools/gen_golden-style drivers, tests) -- which would otherwise train up to
         K - 1 steps on stale rows, stale statistics or a stale bound without any error."""
         nt = self.normalize_tuple
-        return (self.memory.ring.version, self.memory.cur_capacity, None if nt is None else (id(nt[0]), id(nt[1]), float(nt[2])))
+        # (+ the target policy, whose actions for the prepared steps are computed at prefetch time: object and in-place version)
+        pol = None if self.actor is None else (id(self.actor), self.actor.arena.data._version)
+        return (self.memory.ring.version, self.memory.cur_capacity, None if nt is None else (id(nt[0]), id(nt[1]), float(nt[2])), pol)
 
     def _norm_key(self):
         """Part of every graph key: a captured gather has the ADDRESSES of the statistics baked in (update() keeps them stable by
@@ -397,6 +399,13 @@ class PQLVLearner:
         ws["idx"] = torch.zeros(B, dtype=torch.int64, device=dev)
         ws["draw"] = torch.zeros((B, A), **f)
         ws["acts_a"] = torch.empty(al.acts_floats(B), **f)
+        # The target policy does not change between two hand-offs (pql_v_learner.py:117-122 is the only place the reference assigns
+        # it), its inputs for the next K steps are the tiles gathered ahead and its noise the draws made ahead: the K steps' target
+        # actions come from ONE forward launch over K x B rows at prefetch time (64-row tiles on every CU, one launch's fixed cost
+        # instead of K) and the step itself starts at the target critic (algo.actor_ahead).
+        ws["actor_ahead"] = bool(want and K > 1 and _cfg_get(self.cfg.algo, "actor_ahead", True))
+        if ws["actor_ahead"]:
+            ws["a_out_all"] = torch.empty((K * B, L.ld(A)), **f)
         ws["acts_t"] = torch.empty(cl.acts_floats(B), **f)
         ws["acts_c"] = torch.empty(cl.acts_floats(B), **f)
         ws["dy"] = torch.zeros((2, B, cl.ld_out), **f)
@@ -466,6 +475,11 @@ class PQLVLearner:
         K, B = ws["K"], ws["B"]
         self._ahead.refill(self.memory.cur_capacity)
         self._gather(ws, self._ahead.idx, K * B, ws["x_sa_all"], ws["xn_sa_all"], ws["rew_all"], ws["done_all"])
+        if ws["actor_ahead"]:   # a' = clamp(tanh(actor(s')) + clamp(0.8 N(0,1), +-0.2), +-1) of all K steps -> action columns of their tiles
+            algo, O = self.cfg.algo, self.memory.ring.O
+            xn = ws["xn_sa_all"].view(K * B, ws["ld_sa"])
+            mlp_forward_raw(self.actor.layout, self.actor.arena.data, xn, L.ACT_TANH_NOISE, self._ahead.normal.view(K * B, -1),
+                            algo.noise.tgt_pol_std, algo.noise.tgt_pol_noise_bound, ws["a_out_all"], xn[:, O:], packed=self.pk_actor, stash_all=2)
         self._ahead_stamp = self._data_stamp()
 
     def _step_kernels(self, ws, idx, draw, upto_backward=False, tiles=None, part=None):
@@ -478,6 +492,7 @@ class PQLVLearner:
         O = self.memory.ring.O
         st = L.stream(dev)
         actor_in_sa = self.pk_actor is not None and self.pk_actor.tensor is not None
+        tiles_ahead = tiles is not None
         if tiles is None:
             tiles = ws["slots"][0]
             if part in (None, 0):
@@ -492,8 +507,9 @@ class PQLVLearner:
             # target policy smoothing (:63-71): a' written into the action columns of the target critic's input.
             # The two no-grad chains (actor, target critic) skip the activation stash; the critic keeps it for backward.
             xn_act = ws["xn_sa"][:, O:]
-            mlp_forward_raw(al, self.actor.arena.data, ws["xn_sa"] if actor_in_sa else ws["xn_obs"], L.ACT_TANH_NOISE, draw, algo.noise.tgt_pol_std,
-                            algo.noise.tgt_pol_noise_bound, ws["acts_a"], xn_act, packed=self.pk_actor, stash_all=False)
+            if not (tiles_ahead and ws["actor_ahead"]):   # (tiles gathered ahead already hold a': _prefetch)
+                mlp_forward_raw(al, self.actor.arena.data, ws["xn_sa"] if actor_in_sa else ws["xn_obs"], L.ACT_TANH_NOISE, draw, algo.noise.tgt_pol_std,
+                                algo.noise.tgt_pol_noise_bound, ws["acts_a"], xn_act, packed=self.pk_actor, stash_all=False)
             mlp_forward_raw(cl, self.critic_target.arena.data, ws["xn_sa"], L.ACT_NONE, acts=ws["acts_t"], packed=self.pk_target,
                             stash_all=False)
             if ws["td_fwd"] > 0:

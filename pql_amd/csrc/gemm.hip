@@ -1014,7 +1014,8 @@ static int fused_rows(const PqlMlpDesc* d, int buf_ld, int64_t b) {
 }
 
 static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const float* packed, const float* x, int64_t ldx,
-                               int64_t b, float* acts, int stash_all, hipStream_t st, const FusedHead* head = nullptr) {
+                               int64_t b, float* acts, int stash_all, hipStream_t st, const FusedHead* head = nullptr,
+                               bool out_only = false) {
   FusedP p = {};
   int buf_ld = 0;
   if (!fusable(d, &buf_ld)) return PQLK_E_UNSUPPORTED;
@@ -1036,7 +1037,7 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
     pqlk_mlp_layer_offsets(d, L - 1, &w_off, &b_off);
     pqlk_mlp_act_offset(d, b, 0, L - 1, &a_off, &a_ld);
     p.head_n = head->n; p.head_epi = head->epi; p.head_ld = (int)a_ld; p.ld_out2 = (int)head->ld_out2;
-    p.head_w_off = w_off; p.head_b_off = b_off; p.head_a_off = a_off;
+    p.head_w_off = w_off; p.head_b_off = b_off; p.head_a_off = out_only ? 0 : a_off;   // out_only: `acts` IS the output block
     p.draw = head->draw; p.out2 = head->out2; p.noise_std = head->noise_std; p.noise_clip = head->noise_clip;
     p.qc = head->n == 1 ? head->qc : nullptr;
     if (head->td_dz) {
@@ -1081,18 +1082,21 @@ extern "C" int pqlk_mlp_forward(const PqlMlpDesc* d, const float* params, const 
   PQLK_REQUIRE(out_act == PQLK_ACT_NONE || out_act == PQLK_ACT_TANH || out_act == PQLK_ACT_TANH_NOISE, PQLK_E_UNSUPPORTED);
   if (out_act == PQLK_ACT_TANH_NOISE) PQLK_REQUIRE(draw, PQLK_E_NULL);
   if (out2) PQLK_REQUIRE(d->n_nets == 1 && ld_out2 >= d->dims[d->n_layers], PQLK_E_SHAPE);
+  PQLK_REQUIRE(stash_all >= 0 && stash_all <= PQLK_STASH_OUTPUT_ONLY, PQLK_E_RANGE);
   const int64_t net_stride = pqlk_mlp_net_stride(d);
   const int L = d->n_layers;
   int l_first = 0;
+  static const bool no_head = getenv("PQLK_NO_FUSED_HEAD") != nullptr;   // tuning / A-B switch
+  const bool out_only = stash_all == PQLK_STASH_OUTPUT_ONLY;   // `acts` = the output block alone: fused stack + fused head only
+  if (out_only) PQLK_REQUIRE(packed && fusable(d, nullptr) && head_fusable(d) && !no_head, PQLK_E_UNSUPPORTED);
   if (packed && fusable(d, nullptr)) {  // all hidden layers in one launch, activations resident in LDS
     PQLK_REQUIRE(pqlk_aligned16(packed), PQLK_E_ALIGN);
     FusedHead head = {};
-    static const bool no_head = getenv("PQLK_NO_FUSED_HEAD") != nullptr;   // tuning / A-B switch
     if (head_fusable(d) && !no_head) {   // ... and the output layer too
       head.n = d->dims[L]; head.epi = out_act; head.draw = draw; head.noise_std = noise_std; head.noise_clip = noise_clip;
       head.out2 = out2; head.ld_out2 = ld_out2;
     }
-    rc = launch_fused_hidden(d, params, packed, x, ldx, b, acts, stash_all ? 1 : 0, pqlk_s(stream), &head);
+    rc = launch_fused_hidden(d, params, packed, x, ldx, b, acts, stash_all == 1 ? 1 : 0, pqlk_s(stream), &head, out_only);
     if (rc) return rc;
     l_first = head.n > 0 ? L : L - 1;
   }

@@ -108,14 +108,15 @@ class PackedWeights:
 def mlp_forward_raw(layout: ArenaLayout, arena, x_pad, out_act=L.ACT_NONE, draw=None, noise_std=0.0, noise_clip=0.0,
                     acts=None, out2=None, packed: PackedWeights = None, stash_all=True):
     """Launch the forward; returns the activation stash (last block = (n_nets, B, ld_out) output).
-    packed: PackedWeights refreshed from `arena` -> fused hidden layers; None -> one GEMM launch per layer."""
+    packed: PackedWeights refreshed from `arena` -> fused hidden layers; None -> one GEMM launch per layer.
+    stash_all=2 (PQLK_STASH_OUTPUT_ONLY): `acts` is the (n_nets, B, ld_out) output block itself, nothing else is written."""
     B = x_pad.shape[0]
     dev = x_pad.device
     if acts is None:
         acts = torch.empty(layout.acts_floats(B), dtype=torch.float32, device=dev)
     pk = packed.tensor if packed is not None else None
     with torch.cuda.device(dev):
-        L.check(L.lib.pqlk_mlp_forward(C.byref(layout.desc), L.ptr(arena), L.ptr(pk), 1 if stash_all else 0, L.ptr(x_pad),
+        L.check(L.lib.pqlk_mlp_forward(C.byref(layout.desc), L.ptr(arena), L.ptr(pk), 2 if stash_all == 2 else (1 if stash_all else 0), L.ptr(x_pad),
                                        x_pad.stride(0), B, out_act, L.ptr(draw), float(noise_std), float(noise_clip),
                                        L.ptr(acts), L.ptr(out2), out2.stride(0) if out2 is not None else 0, L.stream(dev)))
     return acts

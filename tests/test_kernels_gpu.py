@@ -965,6 +965,45 @@ def test_dpg_backward_fused_matches_the_separate_launches(dev, hidden, A, B):
         assert mn[0] == int((own & 1).sum()) and mn[1] == int(((own >> 1) & 1).sum()) and mn[2] % 128 == 0 and mn[3] % 128 == 0
 
 
+def test_output_only_forward_over_k_batches_equals_the_per_batch_forwards(dev):
+    """algo.actor_ahead: the target policy's noised actions of the next K V-learner steps come from ONE forward launch over K x B rows
+    (stash_all = PQLK_STASH_OUTPUT_ONLY: `acts` is the output block, nothing else is written).  At K x B = 65 536 rows the launch
+    runs 64-row tiles (two row tiles share every weight fragment), the per-step launch of 8192 rows 32-row tiles: the same k-ordered
+    fp32 fma chain per output element, so the actions -- in the output block and dropped into the critic-input tiles -- must be
+    BIT-identical to K separate calls."""
+    from pql_amd import _lib as L
+    from pql_amd.models.mlp import ArenaLayout, PackedWeights, mlp_forward_raw, output_view
+    O, A, B, K = 88, 16, 8192, 8
+    lay = ArenaLayout([O, 512, 512, 256, A], 1)
+    g = torch.Generator(device=dev).manual_seed(5)
+    arena = torch.zeros(lay.total, device=dev)
+    for l in range(lay.n_layers):
+        bound = 1.0 / np.sqrt(lay.dims[l])
+        lay.weight(arena, 0, l).copy_((torch.rand(lay.weight(arena, 0, l).shape, device=dev, generator=g) * 2 - 1) * bound)
+        lay.bias(arena, 0, l).copy_((torch.rand(lay.dims[l + 1], device=dev, generator=g) * 2 - 1) * bound)
+    pk = PackedWeights(lay, dev).refresh(arena)
+    ld_sa = L.ld(O + A)
+    tiles = torch.zeros((K, B, ld_sa), device=dev)
+    tiles[:, :, :O] = torch.randn((K, B, O), device=dev, generator=g)
+    draw = torch.randn((K, B, A), device=dev, generator=g)
+    ref_tiles = tiles.clone()
+    ref_out = []
+    for k in range(K):
+        acts = mlp_forward_raw(lay, arena, ref_tiles[k], L.ACT_TANH_NOISE, draw[k], 0.8, 0.2, out2=ref_tiles[k][:, O:], packed=pk, stash_all=False)
+        ref_out.append(output_view(lay, acts, B)[0].clone())
+    out = torch.full((K * B, L.ld(A)), 7.0, device=dev)
+    flat = tiles.view(K * B, ld_sa)
+    mlp_forward_raw(lay, arena, flat, L.ACT_TANH_NOISE, draw.view(K * B, A), 0.8, 0.2, out, flat[:, O:], packed=pk, stash_all=2)
+    torch.cuda.synchronize()
+    assert torch.equal(tiles, ref_tiles)
+    assert torch.equal(out.view(K, B, -1), torch.stack(ref_out))
+    assert float(tiles[:, :, O:O + A].abs().max()) <= 1.0 and float(tiles[:, :, O:O + A].abs().mean()) > 0.05
+    # the mode needs the fused stack + fused head: refused otherwise instead of writing past a small buffer
+    rc = L.lib.pqlk_mlp_forward(C.byref(lay.desc), L.ptr(arena), None, 2, L.ptr(flat), ld_sa, K * B, L.ACT_TANH, None, 0.0, 0.0, L.ptr(out), None, 0,
+                                L.stream(dev))
+    assert rc == 5   # PQLK_E_UNSUPPORTED
+
+
 _GEMM_LOOP_SCRIPT = r"""
 import ctypes as C, hashlib, sys
 sys.path.insert(0, {tests!r}); sys.path.insert(0, {root!r})
