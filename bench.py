@@ -75,6 +75,8 @@ def parse():
     ap.add_argument("--override", action="append", default=[], metavar="KEY=VALUE",
                     help="extra cfg override in the entry point's syntax (A/B switches: algo.actor_ahead=False, algo.dpg_fused=False ...); "
                          "recorded in config.overrides")
+    ap.add_argument("--gather-event-probe", action="store_true", help="(with --no-roofline, under rocprofv3 --kernel-trace) time the K-batch gather "
+                    "with HIP events around single eager launches and print it: calibration of roofline_gather's method against the trace")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true",
                     help="skip the roofline / free-running sections after the timed blocks (rocprofv3 kernel-trace runs: the CSV's "
@@ -471,6 +473,79 @@ def isolated_launch_ms(launch, device, n=16, sets=4, context=None, evict_mb=384)
     return (ta[2] - tb[2]) / n
 
 
+def launch_event_us(launch, device, n=16, sets=4, context=None):
+    """Duration of ONE launch from HIP events recorded right around it on the stream it runs on, eager (no graph), `context()` between
+    two launches as in isolated_launch_ms -- minus the same interval around a one-block no-op launch of this library (what an
+    event pair and a dispatch cost by themselves), plus that no-op's own ~1 us.  This is the per-kernel duration rocprofv3
+    --kernel-trace reports (begin of the dispatch to its completion signal), obtained in-process."""
+    from pql_amd import _lib as L
+    tiny_a, tiny_b = torch.zeros(64, device=device), torch.zeros(64, device=device)
+
+    def null():
+        L.check(L.lib.pqlk_polyak(L.ptr(tiny_a), L.ptr(tiny_b), 64, 0.5, L.stream(device)))
+
+    def run(fn):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for i, (e0, e1) in enumerate(ev):
+            if context is not None:
+                context()
+            e0.record()
+            fn(i)
+            e1.record()
+        ev[-1][1].synchronize()
+        t = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in ev)
+        return t[len(t) // 2]
+    with torch.cuda.device(device):
+        run(lambda i: launch(i, i % sets))   # warm
+        t_launch = run(lambda i: launch(i, i % sets))
+        t_null = run(lambda i: null())
+    return t_launch, t_null
+
+
+NULL_LAUNCH_US = 3.4   # duration rocprofv3 --kernel-trace reports for the one-block no-op below (k_polyak over 64 floats; profiles/README.md)
+
+
+def learner_gather_us(learner, runs=12):
+    """Duration of the replay-gather launch THE LEARNER ITSELF issues -- the K-batch launch of `_prefetch`, into the learner's own
+    tiles, between the last step of one run and the first of the next -- while the learner runs its steps the way the schedule
+    issues them (`learn_many(K)`): HIP events are recorded right around that one launch on the learner's stream, and right around a
+    one-block no-op launch of this library behind it; kernel duration = (interval around the gather) - (interval around the no-op:
+    what an event pair + a dispatch cost) + the no-op's own duration (NULL_LAUNCH_US).  Checked against rocprofv3's per-dispatch
+    begin/end stamps of the same launches: 27.6 vs 27.3 us (gpurun_out r4j; tests/test_profiles_cpu.py holds the committed bench
+    line to the committed kernel trace within 5 %).  Returns (us per gather launch, rows per launch)."""
+    from pql_amd import _lib as L
+    B = int(learner.cfg.algo.batch_size)
+    ws = learner._workspace(B)
+    K = int(ws["K"])
+    dev = learner.device
+    tiny_a, tiny_b = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+    orig = learner._gather
+    ev, rows = [], [0]
+
+    def timed(ws_, idx, n_rows, *tiles):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        e[0].record()
+        orig(ws_, idx, n_rows, *tiles)
+        e[1].record()
+        e[2].record()
+        L.check(L.lib.pqlk_polyak(L.ptr(tiny_a), L.ptr(tiny_b), 64, 0.5, L.stream(dev)))
+        e[3].record()
+        ev.append(e)
+        rows[0] = int(n_rows)
+
+    learner._gather = timed
+    try:
+        with torch.cuda.device(dev):
+            for _ in range(runs + 2):
+                learner.learn_many(K)
+            learner.synchronize()
+    finally:
+        del learner._gather
+    tg = sorted(e[0].elapsed_time(e[1]) * 1e3 for e in ev[2:])
+    tn = sorted(e[2].elapsed_time(e[3]) * 1e3 for e in ev[2:])
+    return tg[len(tg) // 2] - tn[len(tn) // 2] + NULL_LAUNCH_US, rows[0]
+
+
 def gather_isolated_ms(v, batches, n=16, sets=4, in_step=True):
     """The V-learner's K-batch replay gather as ONE isolated launch (see isolated_launch_ms): between two launches, the forward +
     backward launches of a V step (`in_step`, what the schedule does) or the clean read sweep."""
@@ -491,6 +566,8 @@ def gather_isolated_ms(v, batches, n=16, sets=4, in_step=True):
         L.check(L.lib.pqlk_replay_gather_fused(C.byref(v.memory.ring.desc), L.ptr(idx[i]), rows, L.ptr(mean), L.ptr(var), eps, GATHER_FLAGS,
                                                L.ptr(t["x_sa"]), ws["ld_sa"], L.ptr(t["xn_sa"]), L.ptr(t["xn_obs"]), ws["ld_o"],
                                                L.ptr(t["rew"]), L.ptr(t["done"]), L.stream(v.device)))
+    if in_step == "events":
+        return launch_event_us(launch, v.device, n, sets, context=v_section(v))
     return isolated_launch_ms(launch, v.device, n, sets, context=v_section(v) if in_step else None)
 
 
@@ -815,6 +892,10 @@ def main():
         "gflop_per_v_step": f_v / 1e9, "gflop_per_p_step": f_p / 1e9,
     }
     if rank == 0 and args.no_roofline:
+        if args.gather_event_probe:
+            K = int(v._workspace(args.batch)["K"])
+            t_l, t_n = gather_isolated_ms(v, K, in_step="events")
+            print(f"[gather-event-probe] events around one eager launch inside a V step: {t_l:.2f} us; around a one-block no-op: {t_n:.2f} us", file=sys.stderr)
         emit(line)
     elif rank == 0:
         traffic, traffic_src = {}, None
@@ -852,33 +933,49 @@ def main():
         # the replay gather as the schedule launches it: one launch for the next K V-steps (K = 1 in the per-step torch-RNG mode)
         K = int(v._workspace(args.batch)["K"])
         gms_b2b = gather_ms(v, K)
-        gms = gather_isolated_ms(v, K)
+        alone = getattr(v, "dp", False) or v._ahead is None
+        if alone:
+            # data parallel: a learner step is collective (the other ranks wait at the barrier below), so rank 0 cannot run its learner
+            # alone; algo.rng=torch: the per-step gather sits inside the step's hipGraph, where no event can be recorded around it --
+            # the launch is timed one at a time behind a clean read sweep instead (graph differencing)
+            g_us, g_rows = gather_isolated_ms(v, K, in_step=False) * 1e3, K * args.batch
+        else:
+            g_us, g_rows = learner_gather_us(v)
+        gms = g_us * 1e-3
         rec_ld = v.memory.ring.rec_ld
-        per_batch = args.batch * ((2 * O + A) * 4 + 4 + 1 + 8 + (2 * O + A) * 4 + 4 + 4)   # 1557 B/sample @cfg2
-        alg_bytes = K * per_batch
-        line["roofline_gather"] = {"bound": "hbm", "kernel": "k_replay_gather_fused", "achieved": alg_bytes / (gms * 1e-3) / 1e9,
+        per_row = (2 * O + A) * 4 + 4 + 1 + 8 + (2 * O + A) * 4 + 4 + 4   # 1557 B/sample @cfg2
+        per_batch = args.batch * per_row
+        alg_bytes = g_rows * per_row
+        line["roofline_gather"] = {"bound": "hbm", "kernel": "k_replay_gather_fast (the launch PQLVLearner._prefetch issues: the next K steps' rows)",
+                                   "achieved": alg_bytes / (gms * 1e-3) / 1e9,
                                    "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": alg_bytes / (gms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                   "method": "ONE launch at a time, the forward + backward launches of a V step between two gathers (as in the "
-                                             "schedule), 4 rotating output-tile sets; (graph of 16 x [V step, gather]) - (graph of 16 x [V step]), "
-                                             "HIP events, median of 5 interleaved replays",
-                                   "us_per_launch_behind_read_sweep": gather_isolated_ms(v, K, in_step=False) * 1e3,
+                                   "method": ("one launch at a time behind a clean 384-MB read sweep, graph differencing (data parallel or per-step draws: "
+                                              "the learner's own launch cannot be bracketed)" if alone else
+                                              "kernel duration of the learner's OWN gather launch while it runs its steps as the schedule issues them "
+                                              "(learn_many): HIP events right around the launch, minus the same interval around a one-block no-op "
+                                              "launch, plus that no-op's 3.4 us (bench.learner_gather_us); = what rocprofv3 --kernel-trace reports"),
                                    "traffic": traffic.get("gather_per_launch_bytes") if traffic.get("gather_batches_per_launch", 1) == K else None,
                                    "traffic_source": (f"committed profile {traffic_src}, NOT measured in this run") if traffic_src else None,
                                    "algorithmic_bytes": alg_bytes,
-                                   "us_per_launch": gms * 1e3, "batches_per_launch": K, "rows_per_launch": K * args.batch,
-                                   "us_per_batch": gms * 1e3 / K, "record_bytes": rec_ld * 4,
-                                   "frac_back_to_back": alg_bytes / (gms_b2b * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                   "us_per_launch_back_to_back": gms_b2b * 1e3}
+                                   "us_per_launch": gms * 1e3, "batches_per_launch": g_rows // args.batch, "rows_per_launch": g_rows,
+                                   "us_per_batch": gms * 1e3 * args.batch / g_rows, "record_bytes": rec_ld * 4,
+                                   "frac_back_to_back": K * per_batch / (gms_b2b * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                   "us_per_launch_back_to_back": gms_b2b * 1e3,
+                                   "us_added_to_the_v_queue": gather_isolated_ms(v, K) * 1e3,
+                                   "us_added_note": "(graph of 16 x [V step, gather]) - (graph of 16 x [V step]): the launch, its boundary and what "
+                                                    "its 110 MB of traffic cost the step's next kernels in evicted weights and activations"}
         if K > 1:   # the per-step launch (algo.rng=torch, injected draws) for comparison
-            g1 = gather_isolated_ms(v, 1)
-            line["roofline_gather"]["single_batch_launch"] = {"us_per_launch": g1 * 1e3, "frac": per_batch / (g1 * 1e-3) / 1e9 / PEAK_HBM_GBS}
-        if mode == "schedule" and p.ready_to_learn():   # the P-learner's obs gather: read O floats + 8 B, write O floats per sample
-            pms, prows = gather_p_ms(p, True)
+            g1 = gather_isolated_ms(v, 1, in_step=False)
+            line["roofline_gather"]["single_batch_launch"] = {"us_per_launch": g1 * 1e3, "frac": per_batch / (g1 * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                                              "method": "one launch at a time behind a clean read sweep, graph differencing"}
+        if mode == "schedule" and p.ready_to_learn() and not getattr(p, "dp", False) and p._ahead is not None:   # the P-learner's obs gather: read O floats + 8 B, write O floats per sample
+            p_us, prows = learner_gather_us(p)
             pms_b2b, _ = gather_p_ms(p, False)
             p_alg = prows * (2 * O * 4 + 8)
-            line["roofline_gather_p"] = {"bound": "hbm", "kernel": "k_replay_gather_obs", "achieved": p_alg / (pms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS,
-                                         "unit": "GB/s", "frac": p_alg / (pms * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes": p_alg,
-                                         "us_per_launch": pms * 1e3, "rows_per_launch": prows, "method": "as roofline_gather, a P step's forward + backward launches between two gathers",
+            line["roofline_gather_p"] = {"bound": "hbm", "kernel": "k_replay_gather_obs (the launch PQLPLearner._prefetch issues)",
+                                         "achieved": p_alg / (p_us * 1e-6) / 1e9, "peak": PEAK_HBM_GBS,
+                                         "unit": "GB/s", "frac": p_alg / (p_us * 1e-6) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes": p_alg,
+                                         "us_per_launch": p_us, "rows_per_launch": prows, "method": "as roofline_gather, on the P-learner's queue",
                                          "frac_back_to_back": p_alg / (pms_b2b * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                          "us_per_launch_back_to_back": pms_b2b * 1e3}
         note("roofline sections measured")

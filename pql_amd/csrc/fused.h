@@ -367,8 +367,10 @@ __device__ __forceinline__ void fused_head(const FusedP& p, const float* __restr
   }
 }
 
-// R row tiles of 32 per block; TM = widest per-wave tile count any layer needs (2: widths <= 512, 4: <= 1024)
-template <int R, int TM>
+// R row tiles of 32 per block; TM = widest per-wave tile count any layer needs (2: widths <= 512, 4: <= 1024).
+// OUT_ONLY: the forward-only instantiation behind PQLK_STASH_OUTPUT_ONLY (no stash, no TD head: the launch that serves K learner
+// steps at once, e.g. the target policy's K x B rows) -- a kernel of its own also in the profiler's per-kernel tables.
+template <int R, int TM, bool OUT_ONLY = false>
 __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
   // four tiles per wave: 16 MFMAs per step already cover the L2 latency with a 2-deep ring (and 4 x 4 quads would spill)
   constexpr int NW = FUSED_NW, D = TM >= 4 ? 2 : PQLK_FUSED_DEEP;
@@ -391,7 +393,7 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
   const float* __restrict__ pparams = p.params;
   const float* __restrict__ ppacked = p.packed;
   float* __restrict__ pacts = p.acts;
-  const int pstash = p.stash_all;
+  const int pstash = OUT_ONLY ? 0 : p.stash_all;
   const int row0 = tile * 32 * R;
   const bool full_tile = row0 + 32 * R <= p.B;
   const int buf_ld4 = p.buf_ld >> 2;
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
       fused_layer<R, 1, TM, D>(bq, buf_ld4, K8, K8s, ntiles, packed_l, bias_l, gout, N, row0, p.B, wave, lane_l, packed_n, K8n, ntiles_n,
                                tpw_n, gprev, nprev4);
   }
-  if (p.head_n > 0) fused_head<R>(p, pparams, pacts, net, row0, buf_ld4, wave, lane);   // the LDS buffer holds the last hidden layer's output
+  if (p.head_n > 0) fused_head<R, !OUT_ONLY>(p, pparams, pacts, net, row0, buf_ld4, wave, lane);   // the LDS buffer holds the last hidden layer's output
 }
 
 // arena -> fragment-ordered copy of the hidden layers' weights (one thread per element; 1-3 M elements); ONE launch for all

@@ -1052,8 +1052,9 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
   const int R = fused_rows(d, buf_ld, b);
   static PqlkPerDeviceOnce attr_once;
   if (int rc = attr_once.run([&] {
-        const void* ks[3] = {reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 2>), reinterpret_cast<const void*>(&k_mlp_fwd_fused<2, 2>),
-                             reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 4>)};
+        const void* ks[6] = {reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 2>), reinterpret_cast<const void*>(&k_mlp_fwd_fused<2, 2>),
+                             reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 4>), reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 2, true>),
+                             reinterpret_cast<const void*>(&k_mlp_fwd_fused<2, 2, true>), reinterpret_cast<const void*>(&k_mlp_fwd_fused<1, 4, true>)};
         for (const void* k : ks) {
           hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           if (e != hipSuccess) return -(int)e;
@@ -1063,7 +1064,11 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
     return rc;
   const size_t shmem = fused_lds_bytes(d, buf_ld, R);
   dim3 grid((unsigned)(((b + 32 * R - 1) / (32 * R)) * d->n_nets)), block(64 * FUSED_NW);
-  if (wide) hipLaunchKernelGGL((k_mlp_fwd_fused<1, 4>), grid, block, shmem, st, p);
+  if (out_only) {
+    if (wide) hipLaunchKernelGGL((k_mlp_fwd_fused<1, 4, true>), grid, block, shmem, st, p);
+    else if (R == 2) hipLaunchKernelGGL((k_mlp_fwd_fused<2, 2, true>), grid, block, shmem, st, p);
+    else hipLaunchKernelGGL((k_mlp_fwd_fused<1, 2, true>), grid, block, shmem, st, p);
+  } else if (wide) hipLaunchKernelGGL((k_mlp_fwd_fused<1, 4>), grid, block, shmem, st, p);
   else if (R == 2) hipLaunchKernelGGL((k_mlp_fwd_fused<2, 2>), grid, block, shmem, st, p);
   else hipLaunchKernelGGL((k_mlp_fwd_fused<1, 2>), grid, block, shmem, st, p);
   PQLK_LAUNCH_CHECK();
@@ -1614,7 +1619,12 @@ extern "C" int pqlk_dpg_backward_fused(const PqlMlpDesc* d, const float* params,
     p.ncols_store = p.ldc;
     p.groups = 2; p.zsum = 0; p.epi = EPI_DELU;
     p.perm = perm; p.mn = mn;
-    rc = launch_gemm<MODE_DX, 128, 64, EPI_DELU>(p, 1, st);
+    // (PQLK_COMPACT_TILE=1 / 2: 128 x 128 / 64 x 64 tiles, A/B switch -- measured again in round 4, `profiles/r04_*`)
+    static const int ctile = [] { const char* e = getenv("PQLK_COMPACT_TILE"); return e ? atoi(e) : 0; }();
+    const bool small = ctile == 2 || (ctile == 3 && l == L - 2) || (ctile == 4 && l != L - 2);   // 3 / 4: 64 x 64 for the first / the later products only
+    if (ctile == 1) rc = launch_gemm<MODE_DX, 128, 128, EPI_DELU>(p, 1, st);
+    else if (small) rc = launch_gemm<MODE_DX, 64, 64, EPI_DELU>(p, 1, st);
+    else rc = launch_gemm<MODE_DX, 128, 64, EPI_DELU>(p, 1, st);
     if (rc) return rc;
     flip ^= 1;
   }

@@ -499,7 +499,8 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
                                         pqlk_stream_t stream) {
   const int clamp5 = flags & PQLK_GATHER_CLAMP5;
   const int write_pads = (flags & PQLK_GATHER_PADS_ZERO) ? 0 : 1;
-  const int tune_R = (flags >> 8) & 15, tune_wpc = (flags >> 12) & 63, nt_loads = ((flags & PQLK_GATHER_NT_LOADS) ? 1 : 0) | ((flags & PQLK_GATHER_NT_STORES) ? 2 : 0);
+  const int tune_R = (flags >> 8) & 15, tune_wpc = (flags >> 12) & 63;
+  int nt_loads = ((flags & PQLK_GATHER_NT_LOADS) ? 1 : 0) | ((flags & PQLK_GATHER_NT_STORES) ? 2 : 0);
   PQLK_REQUIRE(ring && ring->records && idx, PQLK_E_NULL);
   PQLK_REQUIRE(ring->obs_dim > 0 && ring->capacity > 0 && b >= 0, PQLK_E_SHAPE);
   RecLayout L = rec_layout(ring->obs_dim, ring->act_dim);
@@ -544,6 +545,11 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
     int64_t fb = (b + rows_blk - 1) / rows_blk;
     const int wpc = tune_wpc ? tune_wpc : 12;
     if (fb > 256 * (int64_t)wpc / 4) fb = 256 * (int64_t)wpc / 4;
+    // Launches whose record reads alone exceed what the 256-MB Infinity Cache can hold beside the output tiles (cfg #5 x 8: 262 144
+    // rows x 1 KiB) take the records with non-temporal loads: they are read once and would only push the tiles out.  Round 4,
+    // tools/bench_gather.py cfg5x8: 150 -> 98 us back to back, 129 -> 123 us one launch at a time; cfg #2 x 8 (59 MB of records):
+    // no difference either way, left alone.
+    if (!tune_R && !tune_wpc && b * (int64_t)L.ld * 4 > ((int64_t)192 << 20)) nt_loads |= 1;
     const dim3 g((unsigned)fb), t(256);
 #define PQLK_GATHER_FAST(NORM, RR) \
     hipLaunchKernelGGL((k_replay_gather_fast<NORM, RR>), g, t, 0, pqlk_s(stream), ring->records, L, ring->capacity, idx, b, mean, var, \

@@ -156,7 +156,9 @@ def main(cfg):
                 time.sleep(sim_wait)
         else:
             # (issued per learner: the steps of one learner between two hand-offs are ONE hipGraph on its queue -- learn_many --
-            #  and the two queues are independent, so this is the interleaved V, V, P, V, V, P ... order as far as results go)
+            #  and the two queues are independent, so this is the interleaved V, V, P, V, V, P ... order as far as results go.
+            #  With algo.streams=False there is one queue: the 4 P steps then start after all 8 V steps.  Under data parallelism
+            #  the per-iteration order of collectives is V x 8 then P x 4 on every rank -- each learner on its own communicator)
             v_learner.learn_many(v_per_iter)
             p_learner.learn_many(v_per_iter // p_every)
         if rank == 0 and evaluator.parent.poll():

@@ -480,7 +480,8 @@ def test_no_kernel_of_the_library_goes_through_scratch():
         pytest.skip("no llvm-readelf")
     res = kr.resources()
     assert len(res) >= 60
-    for want in ("k_mlp_fwd_fused<1, 2>", "k_mlp_fwd_fused<2, 2>", "k_mlp_fwd_fused<1, 4>", "k_replay_gather_fast<true, 2>", "k_adamw"):
+    for want in ("k_mlp_fwd_fused<1, 2, false>", "k_mlp_fwd_fused<2, 2, false>", "k_mlp_fwd_fused<1, 4, false>", "k_mlp_fwd_fused<2, 2, true>",
+                 "k_replay_gather_fast<true, 2>", "k_replay_gather_obs<true, 4>", "k_dpg_minnet_head", "k_dx_slice<16, 16>", "k_adamw"):
         assert any(want in k for k in res), want
     bad = kr.spilling(res)
     assert not bad, {k: (v.get("vgpr_spill_count"), v.get("private_segment_fixed_size")) for k, v in bad.items()}

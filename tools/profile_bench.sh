@@ -40,6 +40,7 @@ if [ "$2" = "full" ]; then
       --steps 48 --warmup 16 --no-cpu-baseline --no-streams --v-only --repeat 1 --burn-in-ms 0 --no-roofline > /dev/null 2> $OUT/pmc_mfma.err || tail -5 $OUT/pmc_mfma.err
   python3 tools/pmc_mfma.py "$(find $OUT/pmc_mfma -name "*counter_collection.csv" | head -1)" $OUT/pmc_mfma.json > /dev/null
   rm -rf $OUT/pmc_mfma
+  echo "[profile] bench lines"
   python3 bench.py --steps 800 --warmup 96 > $OUT/bench.json 2> $OUT/bench.err
   python3 bench.py --no-cpu-baseline --hidden 512,256,128 > $OUT/bench_hidden_ref.json 2>/dev/null
   python3 bench.py --no-cpu-baseline --task ShadowHand --num-envs 16384 --distl --replay 2000000 --hidden 512,256,128 > $OUT/bench_cfg4.json 2>/dev/null
@@ -47,10 +48,13 @@ if [ "$2" = "full" ]; then
   python3 bench.py --no-cpu-baseline --task Humanoid --batch 32768 --nstep 5 --replay 5000000 --hidden 512,256,128 --steps 200 > $OUT/bench_cfg5.json 2>/dev/null
   python3 bench.py --no-cpu-baseline --task Humanoid --batch 32768 --nstep 5 --replay 5000000 --steps 200 > $OUT/bench_cfg5_hidden512x512x256.json 2>/dev/null
   python3 bench.py --no-cpu-baseline --gpus 2 --layout split2 --share-gpu > $OUT/bench_split2_one_card.json 2>/dev/null
-  python3 bench.py --no-cpu-baseline --gpus 2 --backend gloo --share-gpu --steps 100 2>/dev/null | grep "^{" > $OUT/bench_dp2_gloo_one_card.json
-  python3 bench.py --no-cpu-baseline --gpus 2 --backend gloo --share-gpu --steps 100 --scaling strong 2>/dev/null | grep "^{" > $OUT/bench_dp2_strong_gloo_one_card.json
-  PQL_FORCE_DP=1 python3 bench.py --no-cpu-baseline 2>/dev/null | grep "^{" > $OUT/bench_dp1_rccl_one_rank.json   # (RCCL prints a version banner on stdout)
-  python3 tools/bench_gather.py cfg2 cfg2x8 cfg5x8 cfg4x8 > $OUT/gather_sweep.log 2>&1
+  echo "[profile] multi-rank rehearsals"
+  timeout -k 10 300 python3 bench.py --no-cpu-baseline --gpus 2 --backend gloo --share-gpu --steps 100 2>/dev/null | grep "^{" > $OUT/bench_dp2_gloo_one_card.json
+  timeout -k 10 300 python3 bench.py --no-cpu-baseline --gpus 2 --backend gloo --share-gpu --steps 100 --scaling strong 2>/dev/null | grep "^{" > $OUT/bench_dp2_strong_gloo_one_card.json
+  PQL_FORCE_DP=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline 2>/dev/null | grep "^{" > $OUT/bench_dp1_rccl_one_rank.json   # (RCCL prints a version banner on stdout)
+  echo "[profile] gather sweeps"
+  python3 tools/bench_gather.py cfg2x8 p2x4 cfg5x8 cfg4x8 --quick > $OUT/gather_sweep.log 2>&1
+  tools/probes/bin/gather_limit_probe > $OUT/gather_limit_probe.log 2>&1 || true
   # per-launch timelines of one steady-state V / P step (device clock)
   for m in v p; do
     rocprofv3 --kernel-trace --output-format csv -d $OUT/tl_$m -o tl -- python3 bench.py --$m-only --no-streams --steps 40 --warmup 8 --repeat 1 \
@@ -60,4 +64,5 @@ if [ "$2" = "full" ]; then
   done
   python3 bench.py --no-cpu-baseline --rng torch > $OUT/bench_rng_torch.json 2>/dev/null
   python3 tools/roofline_from_stats.py $OUT/v_only_kernel_stats.csv > $OUT/v_only_roofline.md
+  python3 tools/roofline_from_stats.py $OUT/p_only_kernel_stats.csv --p-only > $OUT/p_only_roofline.md
 fi
