@@ -42,6 +42,8 @@ CASES = {
     "draws 3 steps ahead (not a divisor of 8)": ["task=AllegroHand", "algo.prefetch_steps=3", "algo.prefetch_steps_p=5"],
     "free-running, draws ahead, TD loss as its own launch": ["task=AllegroHand", "algo.async_learners=True", "algo.td_in_head=False"],
     "SAC-style ratios 1:1:4": ["task=AllegroHand", "algo.critic_sample_ratio=4", "algo.critic_actor_ratio=1"],
+    "round-3 launch sequences (no actor-ahead, separate DPG launches)": ["task=AllegroHand", "algo.actor_ahead=False", "algo.dpg_fused=False"],
+    "BASELINE hidden, free-running, 2 steps ahead": ["task=AllegroHand", "algo.hidden_layers=[512,512,256]", "algo.async_learners=True"],
 }
 
 
