@@ -578,7 +578,8 @@ def gather_p_ms(p, isolated=True, n=16, sets=4):
     rows = K * B
     idx = torch.randint(p.cur_capacity, size=(n, rows), device=p.device)
     f = dict(dtype=torch.float32, device=p.device)
-    tiles = [dict(x_sa=torch.zeros((rows, ws["ld_sa"]), **f), x_obs=torch.zeros((rows, ws["ld_o"]), **f)) for _ in range(sets)]
+    tiles = [dict(x_sa=None if ws.get("split_in") else torch.zeros((rows, ws["ld_sa"]), **f), x_obs=torch.zeros((rows, ws["ld_o"]), **f))
+             for _ in range(sets)]   # (split input: the P-learner's gather writes the observations once, into the actor's tile)
 
     def launch(i, s):
         p._gather(ws, idx[i], rows, tiles[s]["x_sa"], tiles[s]["x_obs"])

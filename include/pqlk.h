@@ -296,7 +296,10 @@ int pqlk_dpg_critic_backward(const PqlMlpDesc* d, const float* params, const flo
 /* The P-learner's whole backward through the frozen critic in four launches (round 4; pql_p_learner.py:54-58: actor(obs) ->
  * -critic.get_q_min(obs, a).mean() -> .backward()).  Twin scalar-head critics whose forward is fused (hidden stack + head):
  *   pqlk_mlp_forward_qc        the critic's forward (as pqlk_mlp_forward, out_act none) that ALSO leaves the head outputs compact,
- *                              qc (2, B) = Q1 | Q2 (DoubleQ.get_q1_q2, mlp.py:197-199)
+ *                              qc (2, B) = Q1 | Q2 (DoubleQ.get_q1_q2, mlp.py:197-199).  With x2 != NULL the input is
+ *                              [ x[:, :x2_col0] | x2[:, :dims[0] - x2_col0] ] -- `torch.cat((state, action), dim=1)` (mlp.py:197) read
+ *                              from where the two halves already lie (the actor's input tile, the actor's output block): the
+ *                              P-learner's gather then writes the observations once instead of twice.  x2_col0 % 4 == 0.
  *   pqlk_dpg_backward_fused    (1) DPG loss partials, partition of the batch by the net that attained min(Q1, Q2) and the head's dX
  *                              over compact rows in ONE launch (replaces pqlk_dpg_loss_owner + two launches of
  *                              pqlk_dpg_critic_backward), (2) the compact dX GEMMs, (3) the action slice through tanh' TOGETHER
@@ -309,14 +312,16 @@ int pqlk_dpg_critic_backward(const PqlMlpDesc* d, const float* params, const flo
  *                              head_parts = pqlk_dpg_fused_head_parts(b), head_parts_dev = critic_ws +
  *                              pqlk_dpg_fused_mn_offset(critic, b) floats (a device int[4]; only the partial tiles in use exist).
  * pqlk_dpg_fused_ok = 1 when this critic / actor pair can take the path (else use pqlk_dpg_loss_owner +
- * pqlk_dpg_critic_backward + pqlk_mlp_backward); every entry returns PQLK_E_UNSUPPORTED otherwise.
+ * pqlk_dpg_critic_backward + pqlk_mlp_backward); every entry returns PQLK_E_UNSUPPORTED otherwise.  pqlk_dpg_backward_fused does not
+ * read x (the critic's input): it may be NULL.
  * critic_ws >= pqlk_dpg_backward_ws_floats(critic, b), actor_ws >= pqlk_mlp_bwd_ws_floats(actor, b, splits) floats. */
 int32_t pqlk_dpg_fused_ok(const PqlMlpDesc* critic, const PqlMlpDesc* actor, int64_t b);
 int32_t pqlk_dpg_fused_loss_parts(void);
 int32_t pqlk_dpg_fused_head_parts(int64_t b);
 int64_t pqlk_dpg_fused_mn_offset(const PqlMlpDesc* critic, int64_t b);
 int pqlk_mlp_forward_qc(const PqlMlpDesc* d, const float* params, const float* packed, int32_t stash_all, const float* x,
-                        int64_t ldx, int64_t b, float* acts, float* qc, pqlk_stream_t stream);
+                        int64_t ldx, const float* x2 /* or NULL */, int64_t ldx2, int32_t x2_col0, int64_t b, float* acts, float* qc,
+                        pqlk_stream_t stream);
 int pqlk_dpg_backward_fused(const PqlMlpDesc* critic, const float* params, const float* x, int64_t ldx, int64_t b, const float* acts,
                             const float* qc, float* dz_a, int64_t ld_dz, int32_t dx_col0, const float* a_out, int64_t ld_tanh,
                             float* loss_part, float* critic_ws, int64_t critic_ws_floats, const PqlMlpDesc* actor,

@@ -68,7 +68,7 @@ PROTOTYPES = {
     "pqlk_dpg_fused_loss_parts": (_I32, []),
     "pqlk_dpg_fused_head_parts": (_I32, [_I64]),
     "pqlk_dpg_fused_mn_offset": (_I64, [C.POINTER(PqlMlpDesc), _I64]),
-    "pqlk_mlp_forward_qc": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I32, _P, _I64, _I64, _P, _P, _P]),
+    "pqlk_mlp_forward_qc": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I32, _P, _I64, _P, _I64, _I32, _I64, _P, _P, _P]),
     "pqlk_dpg_backward_fused": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _P, _I64, _P, _P, _I64,
                                           C.POINTER(PqlMlpDesc), _P, _P, _P, _I64, _I32, _P]),
     "pqlk_mlp_backward_tail": (C.c_int, [C.POINTER(PqlMlpDesc), _P, _P, _I64, _I64, _P, _P, _I32, _P, _I64, _P, _P, _I32, _P, _P]),

@@ -171,9 +171,19 @@ class PQLPLearner:
         self._ahead = R.DrawAhead(self.gen, self.device, B, None, K, R.verified(self.device)) if want else None
         self._slot_graphs, self._run_graph = {}, None
         ws["K"] = K
-        ws["x_sa_all"] = torch.zeros((K, B, ws["ld_sa"]), **f)
+        # round 4: loss + partition + compact head in one launch, the actor's head backward inside the action-slice launch
+        # (pqlk_dpg_backward_fused: 16 -> 13 launches per step); needs the loss fold of the optimiser launch and a fused critic forward
+        K_atoms = int(getattr(self.critic, "num_atoms", 1))
+        ws["dpg_fused"] = bool(_cfg_get(self.cfg.algo, "dpg_fused", True) and self._fold_loss and K_atoms == 1 and self.pk_critic is not None
+                               and self.pk_critic.tensor is not None and self.pk_actor is not None and self.pk_actor.tensor is not None
+                               and L.lib.pqlk_dpg_fused_ok(C.byref(cl.desc), C.byref(al.desc), B))
+        # ... and then the critic reads its input where the two halves of torch.cat((obs, action)) already lie -- the actor's input
+        # tile and the actor's output block (pqlk_mlp_forward_qc's second source) -- so the gather writes the observations ONCE
+        # (no [obs | action] tile at all: 42 -> 24 MB moved per 4-step launch at cfg #2)
+        ws["split_in"] = bool(ws["dpg_fused"] and O % 4 == 0 and _cfg_get(self.cfg.algo, "dpg_split_input", True))
+        ws["x_sa_all"] = None if ws["split_in"] else torch.zeros((K, B, ws["ld_sa"]), **f)
         ws["x_obs_all"] = torch.zeros((K, B, ws["ld_o"]), **f)
-        ws["slots"] = [dict(x_sa=ws["x_sa_all"][k], x_obs=ws["x_obs_all"][k]) for k in range(K)]
+        ws["slots"] = [dict(x_sa=None if ws["split_in"] else ws["x_sa_all"][k], x_obs=ws["x_obs_all"][k]) for k in range(K)]
         ws.update(ws["slots"][0])
         ws["idx"] = torch.zeros(B, dtype=torch.int64, device=self.device)
         ws["acts_a"] = torch.empty(al.acts_floats(B), **f)
@@ -186,11 +196,6 @@ class PQLPLearner:
         ws["owner"] = torch.zeros(B, dtype=torch.uint8, device=self.device)   # which net(s) own each sample's min(Q1, Q2)
         ws["bwd_a"] = torch.empty(al.bwd_ws_floats(B, ws["splits"]), **f)
         ws["scratch"] = torch.zeros(2048, **f)
-        # round 4: loss + partition + compact head in one launch, the actor's head backward inside the action-slice launch
-        # (pqlk_dpg_backward_fused: 16 -> 13 launches per step); needs the loss fold of the optimiser launch and a fused critic forward
-        K_atoms = int(getattr(self.critic, "num_atoms", 1))
-        ws["dpg_fused"] = bool(_cfg_get(self.cfg.algo, "dpg_fused", True) and self._fold_loss and K_atoms == 1 and self.pk_critic is not None
-                               and self.pk_critic.tensor is not None and L.lib.pqlk_dpg_fused_ok(C.byref(cl.desc), C.byref(al.desc), B))
         if ws["dpg_fused"]:
             ws["qc"] = torch.zeros((2, B), **f)
             ws["head_parts"] = int(L.lib.pqlk_dpg_fused_head_parts(B))
@@ -229,14 +234,18 @@ class PQLPLearner:
             self._gather(ws, idx, B, tiles["x_sa"], tiles["x_obs"])
         ws = dict(ws, **tiles)
         al, cl = self.actor.layout, self.critic.layout
-        x_act = ws["x_sa"][:, O:]
+        x_act = None if ws["split_in"] else ws["x_sa"][:, O:]   # (split input: the critic reads the action out of the actor's output block)
         mlp_forward_raw(al, self.actor.arena.data, ws["x_obs"], L.ACT_TANH, acts=ws["acts_a"], out2=x_act, packed=self.pk_actor,
                         stash_all=True)
         tail = self._fused_tail   # see PQLVLearner._step_kernels
         a_out = output_view(al, ws["acts_a"], B)  # (1, B, ld_a): tanh output, for the tanh' chain
         if ws["dpg_fused"]:
-            L.check(L.lib.pqlk_mlp_forward_qc(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(self.pk_critic.tensor), 1, L.ptr(ws["x_sa"]),
-                                              ws["ld_sa"], B, L.ptr(ws["acts_c"]), L.ptr(ws["qc"]), st))
+            if ws["split_in"]:
+                L.check(L.lib.pqlk_mlp_forward_qc(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(self.pk_critic.tensor), 1, L.ptr(ws["x_obs"]),
+                                                  ws["ld_o"], L.ptr(a_out), ws["ld_a"], O, B, L.ptr(ws["acts_c"]), L.ptr(ws["qc"]), st))
+            else:
+                L.check(L.lib.pqlk_mlp_forward_qc(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(self.pk_critic.tensor), 1, L.ptr(ws["x_sa"]),
+                                                  ws["ld_sa"], None, 0, 0, B, L.ptr(ws["acts_c"]), L.ptr(ws["qc"]), st))
             L.check(L.lib.pqlk_dpg_backward_fused(C.byref(cl.desc), L.ptr(self.critic.arena.data), L.ptr(ws["x_sa"]), ws["ld_sa"], B,
                                                   L.ptr(ws["acts_c"]), L.ptr(ws["qc"]), L.ptr(ws["dz_a"]), ws["ld_a"], O, L.ptr(a_out), ws["ld_a"],
                                                   L.ptr(ws["scratch"]), L.ptr(ws["bwd_c"]), ws["bwd_c"].numel(), C.byref(al.desc),

@@ -31,6 +31,8 @@ typedef float f32x16f __attribute__((ext_vector_type(16)));
 
 struct FusedP {
   const float* X;       // (B, ldx) input shared by all nets
+  const float* X2;      // optional second source: input columns [x2_col0, dims[0]) come from X2 (B, ldx2), column c from X2[:, c - x2_col0]
+  int ldx2, x2_col0;    //   (x2_col0 a multiple of 4; torch.cat((obs, action), dim=1) of mlp.py:197 without either a copy or a shared tile)
   const float* params;  // parameter arena (biases are read from here)
   const float* packed;  // fragment-ordered hidden-layer weights
   float* acts;          // activation stash (layout of pqlk_mlp_act_offset)
@@ -427,7 +429,14 @@ __global__ __launch_bounds__(64 * FUSED_NW) void k_mlp_fwd_fused(FusedP p) {
         const int i = i0 + u * 64 * NW;
         const int row = i / cpr, c4 = i - row * cpr;
         v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < total && row0 + row < p.B) v[u] = *reinterpret_cast<const float4*>(pX + (long long)(row0 + row) * p.ldx + 4 * c4);
+        if (i < total && row0 + row < p.B) {
+          const int c = 4 * c4;
+          if (p.X2 && c >= p.x2_col0) {
+            if (c - p.x2_col0 < p.ldx2) v[u] = *reinterpret_cast<const float4*>(p.X2 + (long long)(row0 + row) * p.ldx2 + (c - p.x2_col0));
+          } else if (c < p.ldx) {
+            v[u] = *reinterpret_cast<const float4*>(pX + (long long)(row0 + row) * p.ldx + c);
+          }
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {

@@ -985,6 +985,7 @@ struct FusedHead {   // output layer to run inside the fused launch (n = 0: none
   float* out2;
   int64_t ld_out2;
   float* qc;   // compact copy of a scalar head's output (pqlk_mlp_forward_qc)
+  const float* x2; int64_t ldx2; int x2_col0;   // second input source (pqlk_mlp_forward_qc)
   // TD head (pqlk_mlp_forward_td): see FusedP
   const float* td_qt; const float* td_rew; const float* td_done; float td_gamma_n;
   float* td_dz; float* td_head_part; float* td_loss_part;
@@ -1040,6 +1041,7 @@ static int launch_fused_hidden(const PqlMlpDesc* d, const float* params, const f
     p.head_w_off = w_off; p.head_b_off = b_off; p.head_a_off = out_only ? 0 : a_off;   // out_only: `acts` IS the output block
     p.draw = head->draw; p.out2 = head->out2; p.noise_std = head->noise_std; p.noise_clip = head->noise_clip;
     p.qc = head->n == 1 ? head->qc : nullptr;
+    p.X2 = head->x2; p.ldx2 = (int)head->ldx2; p.x2_col0 = head->x2_col0;
     if (head->td_dz) {
       p.td_qt = head->td_qt; p.td_rew = head->td_rew; p.td_done = head->td_done; p.td_gamma_n = head->td_gamma_n;
       p.td_two_over_b = 2.0f / (float)b;
@@ -1421,7 +1423,22 @@ static bool minnet_ok(const PqlMlpDesc* d, const float* dx, const float* dx_tanh
     if (d->dims[l] % 128 != 0) return false;   // output width of the dX GEMM of layer l + 1: whole 128-column tiles
   return true;
 }
-static int64_t minnet_rows_cap(int64_t b) { return 2 * pqlk_round_up(b, MN_TILE); }   // every sample a tie: both runs full
+static int64_t minnet_rows_cap(int64_t b) { return 2 * pqlk_round_up(b, MN_TILE); }
+
+// Tile shape of the compact dX products (rows = samples partitioned by owning net: b + ties + up to 254 pad rows instead of 2 b).
+// 128 x 128 tiles at two per CU leave a handful of CUs with twice the work (82 -> 63 us on the 512-wide layer with 128 x 64 tiles,
+// round 2).  Round 4 (`profiles/r04_b_compact_tile_ab.log`, alternating runs): 64 x 64 tiles -- four times the blocks of short
+// products (K = 256 / 512) -- run the P-learner alone 2.8 % faster than 128 x 64 (1960-1970 -> 2016-2022 steps/s) and leave the
+// three-stream schedule's `value` where it was (medians 1212 vs 1212): the default.  PQLK_COMPACT_TILE = 0 (128 x 64), 1 (128 x
+// 128), 2 (64 x 64), 3 / 4 (64 x 64 for the first / the later product only) is the A/B switch.
+static int launch_compact_dx(const GemmP& p, bool first, hipStream_t st) {
+  static const int ctile = [] { const char* e = getenv("PQLK_COMPACT_TILE"); return e ? atoi(e) : 2; }();
+  const bool small = ctile == 2 || (ctile == 3 && first) || (ctile == 4 && !first);
+  if (ctile == 1) return launch_gemm<MODE_DX, 128, 128, EPI_DELU>(p, 1, st);
+  if (small) return launch_gemm<MODE_DX, 64, 64, EPI_DELU>(p, 1, st);
+  return launch_gemm<MODE_DX, 128, 64, EPI_DELU>(p, 1, st);
+}
+   // every sample a tie: both runs full
 
 extern "C" int64_t pqlk_dpg_backward_ws_floats(const PqlMlpDesc* d, int64_t b) {
   if (desc_ok(d) || b <= 0) return 0;
@@ -1486,9 +1503,7 @@ extern "C" int pqlk_dpg_critic_backward(const PqlMlpDesc* d, const float* params
     p.ncols_store = p.ldc;
     p.groups = 2; p.zsum = 0; p.epi = EPI_DELU;
     p.perm = perm; p.mn = mn;
-    // 128 x 64 tiles, three blocks per CU: the compact rows are one or two 128-row tiles MORE than b / 128 (each net's run is
-    // padded), so 128 x 128 tiles at two per CU leave a handful of CUs with twice the work (82 -> 63 us on the 512-wide layer)
-    rc = launch_gemm<MODE_DX, 128, 64, EPI_DELU>(p, 1, st);
+    rc = launch_compact_dx(p, l == L - 2, st);
     if (rc) return rc;
     flip ^= 1;
   }
@@ -1544,16 +1559,23 @@ extern "C" int32_t pqlk_dpg_fused_head_parts(int64_t b) { return b > 0 ? (int32_
 
 // The twin scalar-head critic's forward that ALSO leaves the head outputs compact: qc (2, B) = Q1 | Q2 (mlp.py:186-203).
 extern "C" int pqlk_mlp_forward_qc(const PqlMlpDesc* d, const float* params, const float* packed, int32_t stash_all, const float* x,
-                                   int64_t ldx, int64_t b, float* acts, float* qc, pqlk_stream_t stream) {
+                                   int64_t ldx, const float* x2, int64_t ldx2, int32_t x2_col0, int64_t b, float* acts, float* qc,
+                                   pqlk_stream_t stream) {
   int rc = desc_ok(d);
   if (rc) return rc;
   PQLK_REQUIRE(params && packed && x && acts && qc, PQLK_E_NULL);
   PQLK_REQUIRE(b > 0 && b < (1LL << 30), PQLK_E_SHAPE);
-  PQLK_REQUIRE(ldx % 32 == 0 && ldx >= pqlk_ld(d->dims[0]), PQLK_E_ALIGN);
   PQLK_REQUIRE(pqlk_aligned16(params) && pqlk_aligned16(packed) && pqlk_aligned16(x) && pqlk_aligned16(acts) && pqlk_aligned16(qc), PQLK_E_ALIGN);
+  if (x2) {   // input = [ x[:, :x2_col0] | x2[:, :dims[0] - x2_col0] ]: the two halves of torch.cat((obs, action), dim=1) where they lie
+    PQLK_REQUIRE(x2_col0 > 0 && x2_col0 % 4 == 0 && x2_col0 < d->dims[0], PQLK_E_RANGE);
+    PQLK_REQUIRE(ldx % 4 == 0 && ldx >= x2_col0 && ldx2 % 4 == 0 && ldx2 >= d->dims[0] - x2_col0 && pqlk_aligned16(x2), PQLK_E_ALIGN);
+  } else {
+    PQLK_REQUIRE(ldx % 32 == 0 && ldx >= pqlk_ld(d->dims[0]), PQLK_E_ALIGN);
+  }
   PQLK_REQUIRE(d->dims[d->n_layers] == 1 && fusable(d, nullptr) && head_fusable(d) && !getenv("PQLK_NO_FUSED_HEAD"), PQLK_E_UNSUPPORTED);
   FusedHead head = {};
   head.n = 1; head.epi = PQLK_ACT_NONE; head.qc = qc;
+  head.x2 = x2; head.ldx2 = ldx2; head.x2_col0 = x2_col0;
   return launch_fused_hidden(d, params, packed, x, ldx, b, acts, stash_all ? 1 : 0, pqlk_s(stream), &head);
 }
 
@@ -1568,13 +1590,13 @@ extern "C" int pqlk_dpg_backward_fused(const PqlMlpDesc* d, const float* params,
                                        const float* qc, float* dz_a, int64_t ld_dz, int32_t dx_col0, const float* a_out, int64_t ld_tanh,
                                        float* loss_part, float* ws, int64_t ws_floats, const PqlMlpDesc* ad, const float* a_params,
                                        const float* a_acts, float* a_ws, int64_t a_ws_floats, int32_t a_splits, pqlk_stream_t stream) {
-  PQLK_REQUIRE(d && ad && params && x && acts && qc && dz_a && a_out && loss_part && ws && a_params && a_acts && a_ws, PQLK_E_NULL);
+  PQLK_REQUIRE(d && ad && params && acts && qc && dz_a && a_out && loss_part && ws && a_params && a_acts && a_ws, PQLK_E_NULL);   // (x: not read)
   PQLK_REQUIRE(dpg_fused_ok(d, ad, b), PQLK_E_UNSUPPORTED);
   PQLK_REQUIRE(ws_floats >= pqlk_dpg_backward_ws_floats(d, b), PQLK_E_WORKSPACE);
   PQLK_REQUIRE(a_splits >= 1 && a_splits <= 64 && a_ws_floats >= pqlk_mlp_bwd_ws_floats(ad, b, a_splits), PQLK_E_WORKSPACE);
   const int L = d->n_layers, La = ad->n_layers, A = ad->dims[La];
   PQLK_REQUIRE(ld_dz % 32 == 0 && ld_dz >= A && ld_tanh >= A && dx_col0 >= 0 && dx_col0 + A <= d->dims[0], PQLK_E_RANGE);
-  PQLK_REQUIRE(ldx % 32 == 0 && ldx >= pqlk_ld(d->dims[0]), PQLK_E_ALIGN);
+  (void)x; (void)ldx;
   PQLK_REQUIRE(pqlk_aligned16(qc) && pqlk_aligned16(ws) && pqlk_aligned16(a_ws) && pqlk_aligned16(acts) && pqlk_aligned16(a_acts), PQLK_E_ALIGN);
   const int64_t net_stride = pqlk_mlp_net_stride(d);
   const int64_t rows_cap = minnet_rows_cap(b), mld = max_hidden_ld(d);
@@ -1619,12 +1641,7 @@ extern "C" int pqlk_dpg_backward_fused(const PqlMlpDesc* d, const float* params,
     p.ncols_store = p.ldc;
     p.groups = 2; p.zsum = 0; p.epi = EPI_DELU;
     p.perm = perm; p.mn = mn;
-    // (PQLK_COMPACT_TILE=1 / 2: 128 x 128 / 64 x 64 tiles, A/B switch -- measured again in round 4, `profiles/r04_*`)
-    static const int ctile = [] { const char* e = getenv("PQLK_COMPACT_TILE"); return e ? atoi(e) : 0; }();
-    const bool small = ctile == 2 || (ctile == 3 && l == L - 2) || (ctile == 4 && l != L - 2);   // 3 / 4: 64 x 64 for the first / the later products only
-    if (ctile == 1) rc = launch_gemm<MODE_DX, 128, 128, EPI_DELU>(p, 1, st);
-    else if (small) rc = launch_gemm<MODE_DX, 64, 64, EPI_DELU>(p, 1, st);
-    else rc = launch_gemm<MODE_DX, 128, 64, EPI_DELU>(p, 1, st);
+    rc = launch_compact_dx(p, l == L - 2, st);
     if (rc) return rc;
     flip ^= 1;
   }

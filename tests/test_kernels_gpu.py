@@ -915,10 +915,19 @@ def test_dpg_backward_fused_matches_the_separate_launches(dev, hidden, A, B):
     ld_a, splits, st = L.ld(A), default_splits(B), L.stream(dev)
     acts_c = torch.empty(cl.acts_floats(B), device=dev)
     qc = torch.zeros((2, B), device=dev)
-    L.check(L.lib.pqlk_mlp_forward_qc(C.byref(cl.desc), L.ptr(carena), L.ptr(pkc.tensor), 1, L.ptr(x_sa), cl.ld_in, B, L.ptr(acts_c), L.ptr(qc), st))
+    L.check(L.lib.pqlk_mlp_forward_qc(C.byref(cl.desc), L.ptr(carena), L.ptr(pkc.tensor), 1, L.ptr(x_sa), cl.ld_in, None, 0, 0, B, L.ptr(acts_c),
+                                      L.ptr(qc), st))
     acts_ref = mlp_forward_raw(cl, carena, x_sa, L.ACT_NONE, packed=pkc, stash_all=True)
     assert torch.equal(acts_c, acts_ref)                                    # the compact copy changes nothing else
     assert torch.equal(qc, output_view(cl, acts_c, B)[:, :, 0])
+    # split input: [obs | action] read from the actor's input tile and the actor's output block (no concatenated tile): same bits
+    acts_s, qc_s = torch.empty_like(acts_c), torch.zeros_like(qc)
+    L.check(L.lib.pqlk_mlp_forward_qc(C.byref(cl.desc), L.ptr(carena), L.ptr(pkc.tensor), 1, L.ptr(x_obs), al.ld_in, L.ptr(a_out), L.ld(A), O, B,
+                                      L.ptr(acts_s), L.ptr(qc_s), st))
+    assert torch.equal(acts_s, acts_c) and torch.equal(qc_s, qc)
+    rc = L.lib.pqlk_mlp_forward_qc(C.byref(cl.desc), L.ptr(carena), L.ptr(pkc.tensor), 1, L.ptr(x_obs), al.ld_in, L.ptr(a_out), L.ld(A), O + 2, B,
+                                   L.ptr(acts_s), L.ptr(qc_s), st)
+    assert rc == 3   # PQLK_E_RANGE: the split must fall on a 16-byte boundary
     for case in ("natural", "ties", "all_net1"):
         q = output_view(cl, acts_c, B)
         if case == "ties":

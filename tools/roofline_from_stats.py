@@ -56,9 +56,10 @@ def main():
         who = "P"
         table = [
             ("void k_mlp_fwd_fused<1, 2, false>", "actor fused forward (+tanh, action dropped into the critic's input; stashing)", 2.0 * B * macs(actor), "flop"),
-            ("void k_mlp_fwd_fused<2, 2, false>", "frozen twin-critic fused forward on [obs | pi(obs)] (stashing, + compact Q)", 2.0 * B * 2 * macs(crit), "flop"),
+            ("void k_mlp_fwd_fused<2, 2, false>", "frozen twin-critic fused forward on [obs, pi(obs)] (stashing, + compact Q)", 2.0 * B * 2 * macs(crit), "flop"),
             ("k_dpg_minnet_head", "DPG loss + partition by owning net + compact head dX (round 4: one launch)", B * (2 * 4 + 2 * h[2] * 4), "byte"),
-            ("void k_gemm<1, 128, 64", "compact dX GEMMs (+ELU') of the critic's hidden layers 3 and 2: ONE net per sample", 2.0 * B * (h[2] * h[1] + h[1] * h[0]), "flop"),
+            ("void k_gemm<1, 64, 64", "compact dX GEMMs (+ELU') of the critic's hidden layers 3 and 2: ONE net per sample (64 x 64 tiles)", 2.0 * B * (h[2] * h[1] + h[1] * h[0]), "flop"),
+            ("void k_gemm<1, 128, 64", "compact dX GEMMs (+ELU') of the critic's hidden layers 3 and 2: ONE net per sample (128 x 64 tiles)", 2.0 * B * (h[2] * h[1] + h[1] * h[0]), "flop"),
             ("void k_dx_slice<", "action slice of the critic's layer-1 dX through tanh' + the ACTOR's head backward (round 4: one launch)",
              B * (h[0] + 2 * h[2]) * 4.0, "byte"),   # reads dZ1 (h0) + the actor's last hidden layer (h2), writes its dZ (h2): 0.5 GFLOP ride along
             ("void k_gemm<1, 128, 128", "dX GEMMs (+ELU') of the actor's hidden layers 3 and 2", 2.0 * B * (h[2] * h[1] + h[1] * h[0]), "flop"),
@@ -66,7 +67,7 @@ def main():
             ("void k_gemm<2, 64, 64", "dW GEMMs of the actor's layers 3 and 1", 2.0 * B * (h[2] * h[1] + O * h[0]), "flop"),
             ("k_reduce_slabs", "sum of the 16 dW slabs (+ head fold + sum g^2)", params_a * 4.0 * 17, "byte"),
             ("k_adamw", "clip + AdamW + re-pack (+ loss fold)", params_a * 28.0, "byte"),
-            ("void k_replay_gather_obs", "obs gather + normalise into the actor's and the critic's input tiles (one launch per 4 steps)", B * (2 * O * 4 + 8), "byte"),
+            ("void k_replay_gather_obs", "obs gather + normalise into the actor's input tile (one launch per 4 steps)", B * (2 * O * 4 + 8), "byte"),
             ("void k_replay_gather_fused", "obs gather (generic kernel)", B * (2 * O * 4 + 8), "byte"),
             ("k_philox_draws", "randint draws of 4 steps (torch's numbers)", B * 8, "byte"),
         ]
