@@ -513,6 +513,46 @@ def test_draws_ahead_tiles_follow_data_changed_behind_the_learners_back(dev, gra
     assert int(outs[0][4][3:].max()) >= 700      # steps after the direct insert really sampled the new rows
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_p_learner_launch_sequences_agree(dev, graph):
+    """The three forms of the P-learner step -- round 3's 16 launches (`algo.dpg_fused=False`), round 4's 13 with the critic reading
+    a concatenated [obs | action] tile (`algo.dpg_split_input=False`) and with the critic reading the actor's input tile + output
+    block (default) -- on the same seeds and data, AllegroHand shapes at the BASELINE hidden sizes.  The two 13-launch forms run
+    the same kernels on the same values (only where the critic's input rows come from differs): BIT-identical parameters, Adam
+    state and loss ring.  The 16-launch form sums the actor head's dW / db and the loss in another order: equal to rounding."""
+    from pql_amd.algo.pql_p_learner import PQLPLearner
+    from pql_amd.models.mlp import DoubleQ
+    O, A, B, cap, hidden = 88, 16, 2048, 6000, [512, 512, 256]
+    critic = DoubleQ((O,), A, hidden_layers=hidden).to(dev)
+    critic.load_state_dict(_sd(dd.doubleq_state(O, A, 1, 21, hidden=hidden)))
+    norm = (T(dd.uniform((O,), 6, -0.5, 0.5)).to(dev), T(dd.uniform((O,), 7, 0.5, 2.0)).to(dev), 1e-4)
+    outs = {}
+    for name, ov in (("split", {}), ("cat", {"dpg_split_input": False}), ("r3", {"dpg_fused": False})):
+        cfg = make_cfg(False, B=B, memory=cap, hidden=hidden, graph=graph, task="AllegroHand")
+        for k, v_ in ov.items():
+            cfg.algo[k] = v_
+        p = PQLPLearner((O,), A, cfg)
+        p.actor.load_state_dict(_sd(dd.mlp_state(O, A, 11, hidden=hidden)))
+        p.use_private_rng(4321)
+        p.update(critic, T(dd.uniform((5000, O), 33, -3, 3)).to(dev), norm, 0)
+        for _ in range(2):
+            p.learn_many(4)
+        p.learn()
+        torch.cuda.synchronize()
+        ws = p._ws
+        assert ws["dpg_fused"] == (name != "r3") and ws["split_in"] == (name == "split")
+        outs[name] = (p.actor.arena.data.clone(), p.opt.m.clone(), p.opt.v.clone(), p.loss_ring.clone(), p.gen.get_offset())
+    for a, b in zip(outs["split"], outs["cat"]):
+        assert torch.equal(a, b) if torch.is_tensor(a) else a == b
+    ref_, new = outs["r3"], outs["split"]
+    assert ref_[4] == new[4]
+    torch.testing.assert_close(new[3], ref_[3], rtol=1e-5, atol=1e-7)                 # losses of the last five steps
+    # nine AdamW steps of lr 5e-4 on gradients that differ in the last bits: the arenas agree in norm to 1e-4 and on average to 1e-6
+    # (single elements whose gradient is rounding noise may move by a fraction of lr per step: see _check_module)
+    assert float((new[0] - ref_[0]).norm() / ref_[0].norm()) < 1e-4
+    assert float((new[0] - ref_[0]).abs().mean()) < 1e-6
+
+
 def test_graph_replay_matches_eager(dev):
     """hipGraph-captured learn() is the same launch sequence: with equal seeds it must reproduce the eager
     parameters bit for bit (same kernels, same order, same RNG offsets)."""
