@@ -470,3 +470,17 @@ def test_train_pql_data_parallel_wall_clock_stop_is_agreed():
     a, b = outs
     assert a["rollout_iterations"] == b["rollout_iterations"] > 3 and a["critic_sha"] == b["critic_sha"] and a["actor_sha"] == b["actor_sha"]
     assert a["global_steps"] == 2 * (64 * 32 + a["rollout_iterations"] * 64)   # weak: every rank brings its own 64 envs
+
+
+def test_train_pql_data_parallel_four_ranks_on_one_card():
+    """The same branch with FOUR ranks (more than two: the host-staged ring all-reduce then sums the ranks' addends in an order
+    that differs from element to element, and every rank must still receive the same bits): strong mode, 128 envs / 8000 rows /
+    batch 512 split in four; equal counters and bit-equal arenas on all four ranks."""
+    outs = _run_train_pql_ranks(4, ["task.name=Toy", "num_envs=128", "algo.batch_size=512", "algo.memory_size=8000", "max_step=8000",
+                                    "algo.dp_backend=gloo", "algo.dp_share_gpu=True", "algo.graph=True", "algo.eval_freq=1000000",
+                                    "algo.log_freq=1000000"], port=29631)
+    assert [o["rank"] for o in outs] == [0, 1, 2, 3] and all(o["world"] == 4 for o in outs)
+    for k in ("global_steps", "critic_updates", "actor_updates", "rollout_iterations", "critic_sha", "critic_target_sha", "actor_sha"):
+        assert len({o[k] for o in outs}) == 1, (k, [o[k] for o in outs])
+    iters = outs[0]["rollout_iterations"]
+    assert outs[0]["critic_updates"] == 8 * iters and outs[0]["global_steps"] == 128 * 32 + iters * 128

@@ -21,7 +21,9 @@ from pql_amd.replay.simple_replay import RecordRing, ReplayBuffer  # noqa: E402
 # act = -1: the P-learner's obs-only ring (one batch, and the 4-batch launch of the schedule)
 CFG = {"cfg2": (88, 16, 8192, 1_000_000), "cfg5": (108, 21, 32768, 5_000_000), "cfg4": (211, 20, 8192, 2_000_000),
        "cfg2x8": (88, 16, 8 * 8192, 1_000_000), "cfg5x8": (108, 21, 8 * 32768, 5_000_000), "cfg4x8": (211, 20, 8 * 8192, 2_000_000),
-       "p2": (88, -1, 8192, 1_000_000), "p2x4": (88, -1, 4 * 8192, 1_000_000), "p4x4": (211, -1, 4 * 8192, 2_000_000)}
+       "p2": (88, -1, 8192, 1_000_000), "p2x4": (88, -1, 4 * 8192, 1_000_000), "p4x4": (211, -1, 4 * 8192, 2_000_000),
+       # "...s": the obs ring gathered into ONE destination (the actor's input tile: what the P-learner does since round 4)
+       "p2s": (88, -1, 8192, 1_000_000), "p2x4s": (88, -1, 4 * 8192, 1_000_000)}
 SETS, N_ISO = 4, 16
 
 
@@ -39,14 +41,15 @@ def run(name, quick=False, iters=30):
     ring.records.normal_()
     ld_sa, ld_o = L.ld(O + max(A, 16)), L.ld(O)
     f = dict(dtype=torch.float32, device=dev)
-    tiles = [dict(x_sa=torch.zeros((B, ld_sa), **f), xn_sa=None if obs_only else torch.zeros((B, ld_sa), **f),
+    single = name.endswith("s")
+    tiles = [dict(x_sa=None if single else torch.zeros((B, ld_sa), **f), xn_sa=None if obs_only else torch.zeros((B, ld_sa), **f),
                   x_obs=torch.zeros((B, ld_o), **f) if obs_only else None,
                   rew=None if obs_only else torch.zeros(B, **f), done=None if obs_only else torch.zeros(B, **f)) for _ in range(SETS)]
     mean = torch.randn(O, device=dev) * 0.1; var = torch.rand(O, device=dev) + 0.5
     idx = torch.randint(cap, (max(iters, N_ISO) + 2, B), device=dev)
     if obs_only:
         alg = B * (2 * O * 4 + 8)
-        real = B * (ring.rec_ld * 4 + 8 + (ld_sa + ld_o) * 4)
+        real = B * (ring.rec_ld * 4 + 8 + ((0 if name.endswith("s") else ld_sa) + ld_o) * 4)
     else:
         alg = B * ((2 * O + A) * 4 + 4 + 1 + 8 + (2 * O + A) * 4 + 4 + 4)
         real = B * (ring.rec_ld * 4 + 8 + 2 * ld_sa * 4 + 8)
@@ -76,9 +79,9 @@ def run(name, quick=False, iters=30):
 
     print(f"== {name}: O={O} A={A} B={B} rec={ring.rec_ld * 4}B  algorithmic {alg / 1e6:.2f} MB, moved {real / 1e6:.2f} MB", flush=True)
     Rs = (1, 2, 4) if obs_only else (2, 4)
-    wpcs = (8, 16, 32) if obs_only else (8, 12, 16, 24, 32)
+    wpcs = (8, 16, 24, 32) if obs_only else (8, 12, 16, 24, 32)
     if quick:
-        wpcs = (12, 16, 24) if not obs_only else (8, 16)
+        wpcs = (12, 16, 24) if not obs_only else (8, 16, 32)
     for R in Rs:
         for wpc in wpcs:
             for nopad in ((1,) if quick else (0, 1)):
