@@ -327,6 +327,39 @@ def test_c_abi_reports_argument_errors_as_codes():
     for n, inc in ((1, 4), (8192, 4), (8192 * 16, 4), (2048 * 256, 4), (2048 * 256 * 4, 4), (2048 * 256 * 4 + 1, 8), (32768 * 21, 4)):
         assert lib.pqlk_philox_increment(n) == inc, n
     assert lib.pqlk_philox_increment(0) == 0
+    # round-4 entry points: the P-learner's fused backward (eligibility + argument checks: nothing is launched), the output-only
+    # forward, the critic forward with a compact Q copy and a second input source
+    crit, act = L.mlp_desc([104, 512, 512, 256, 1], 2), L.mlp_desc([88, 512, 512, 256, 16], 1)
+    ok = lambda c, a, b=8192: lib.pqlk_dpg_fused_ok(C.byref(c), C.byref(a), b)   # noqa: E731
+    assert ok(crit, act) == 1 and ok(crit, act, 256) == 1
+    assert ok(L.mlp_desc([28, 512, 256, 128, 1], 2), L.mlp_desc([8, 512, 256, 128, 2], 1), 64) == 1       # the toy / golden-trace shapes
+    assert ok(crit, L.mlp_desc([108, 512, 512, 256, 21], 1)) == 0      # Humanoid: 21 actions > 16 -> the separate launches
+    assert ok(L.mlp_desc([104, 512, 512, 256, 51], 2), act) == 0       # C51 heads: the minimum is over expectations
+    assert ok(L.mlp_desc([104, 512, 320, 256, 1], 2), act) == 0        # 320: no whole 128-column tiles in the compact dX chain
+    assert ok(crit, L.mlp_desc([88, 512, 512, 96, 16], 1)) == 0        # actor head over 96 inputs: neither 128 nor 256
+    assert ok(crit, act, 200000) == 0 and ok(crit, act, 0) == 0 and ok(crit, crit) == 0
+    assert lib.pqlk_dpg_fused_loss_parts() == 32 and lib.pqlk_dpg_fused_head_parts(8192) == 512 and lib.pqlk_dpg_fused_head_parts(1000) == 64
+    assert lib.pqlk_dpg_fused_mn_offset(C.byref(crit), 8192) == 2 * 16384 * 512 + 16384 and lib.pqlk_dpg_fused_mn_offset(None, 8192) == -1
+    assert lib.pqlk_dpg_backward_ws_floats(C.byref(crit), 8192) >= lib.pqlk_dpg_fused_mn_offset(C.byref(crit), 8192) + 64 + 16384   # mn + tie0 fit
+    fq = lib.pqlk_mlp_forward_qc
+    assert fq(C.byref(crit), P, None, 1, P, 128, None, 0, 0, 64, P, P, None) == E_NULL                     # needs the packed copy
+    assert fq(C.byref(crit), P, P, 1, P, 128, None, 0, 0, 64, P, None, None) == E_NULL                     # ... and somewhere to put qc
+    assert fq(C.byref(crit), P, P, 1, P, 100, None, 0, 0, 64, P, P, None) == E_ALIGN                       # one source: ldx % 32
+    assert fq(C.byref(crit), P, P, 1, P, 96, P, 32, 90, 64, P, P, None) == E_RANGE                         # split off a 16-byte boundary
+    assert fq(C.byref(crit), P, P, 1, P, 96, P, 8, 88, 64, P, P, None) == E_ALIGN                          # second source narrower than the action
+    assert fq(C.byref(L.mlp_desc([104, 512, 512, 256, 51], 2)), P, P, 1, P, 128, None, 0, 0, 64, P, P, None) == E_UNSUPPORTED
+    bf = lambda c, a, wsf=1 << 40, awsf=1 << 40, qc=P: lib.pqlk_dpg_backward_fused(   # noqa: E731
+        C.byref(c), P, None, 0, 8192, P, qc, P, 32, 88, P, 32, P, P, wsf, C.byref(a), P, P, P, awsf, 16, None)
+    assert bf(crit, act, qc=None) == E_NULL
+    assert bf(crit, L.mlp_desc([108, 512, 512, 256, 21], 1)) == E_UNSUPPORTED
+    assert bf(crit, act, wsf=1024) == WS and bf(crit, act, awsf=1024) == WS
+    bt = lib.pqlk_mlp_backward_tail
+    assert bt(C.byref(act), P, P, 96, 8192, P, None, 16, P, 1 << 40, None, None, 512, None, None) == E_NULL            # no gradient arena
+    assert bt(C.byref(act), P, P, 96, 8192, P, P, 16, P, 1 << 40, P, None, 512, None, None) == E_NULL                  # sumsq without step
+    assert bt(C.byref(act), P, P, 96, 8192, P, P, 16, P, 1 << 40, None, None, 0, None, None) == E_UNSUPPORTED           # no head partials
+    assert bt(C.byref(act), P, P, 96, 8192, P, P, 16, P, 1 << 40, None, None, 1 << 20, None, None) == WS                # more partials than the workspace holds
+    assert lib.pqlk_mlp_forward(C.byref(d), P, None, 3, P, 32, 4, L.ACT_NONE, None, 0.0, 0.0, P, None, 0, None) == E_RANGE         # stash_all in {0, 1, 2}
+    assert lib.pqlk_mlp_forward(C.byref(d), P, None, 2, P, 32, 4, L.ACT_NONE, None, 0.0, 0.0, P, None, 0, None) == E_UNSUPPORTED   # output-only: fused path only
     for code in (E_NULL, E_SHAPE, 3, E_ALIGN, E_UNSUPPORTED, 6):
         assert len(lib.pqlk_strerror(code)) > 2
 
