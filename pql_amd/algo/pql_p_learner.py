@@ -165,7 +165,9 @@ class PQLPLearner:
         f = dict(dtype=torch.float32, device=self.device)
         O, A = self.ring.O, self.action_dim
         al, cl = self.actor.layout, self.critic.layout
-        ws = dict(B=B, ld_sa=L.ld(O + A), ld_o=L.ld(O), ld_a=L.ld(A))
+        # (the actor's input tile is 64-float aligned -- 128 wide for 88 observations: its layer-1 dW product then reads whole 64-column
+        #  tiles of it and takes the LDS-DMA main loop like every other backward GEMM; the extra columns are never written and stay zero)
+        ws = dict(B=B, ld_sa=L.ld(O + A), ld_o=(L.ld(O) + 63) // 64 * 64, ld_a=L.ld(A))
         want = self._want_ahead()   # draws + gathered tiles of the next K steps (see PQLVLearner._workspace)
         K = self._depth if want else 1
         self._ahead = R.DrawAhead(self.gen, self.device, B, None, K, R.verified(self.device)) if want else None

@@ -766,11 +766,16 @@ static bool gemm_plan(GemmP& p, int gz, dim3& grid) {
     }
   }
   if constexpr (KT == 16 && (MODE == MODE_DX || MODE == MODE_DW) && (EPI == EPI_DELU || EPI == EPI_NONE)) {
-    bool dma = gemm_dma_enabled() && p.M % BM == 0 && ncols % BN == 0 && p.N % BN == 0 && !p.C2 && pqlk_aligned16(p.A) &&
+    bool dma = gemm_dma_enabled() && p.M % BM == 0 && !p.C2 && pqlk_aligned16(p.A) &&
                pqlk_aligned16(p.B) && p.lda % 4 == 0 && p.ldb % 4 == 0 && (EPI != EPI_DELU || (p.aux && pqlk_aligned16(p.aux) && p.ldaux % 4 == 0));
-    if (MODE == MODE_DX) dma = dma && p.K % (4 * KT) == 0 && p.K <= p.lda && ncols <= p.ldb && p.sA % 4 == 0 && p.sB % 4 == 0;
-    else dma = dma && p.rows_per_split % (4 * KT) == 0 && p.K % p.rows_per_split == 0 && p.K / p.rows_per_split == p.splits &&
-               p.M <= p.lda && p.N <= p.ldb && p.sA % 4 == 0 && p.sB % 4 == 0;
+    if (MODE == MODE_DX) dma = dma && ncols % BN == 0 && p.N % BN == 0 && p.K % (4 * KT) == 0 && p.K <= p.lda && ncols <= p.ldb && p.sA % 4 == 0 &&
+                               p.sB % 4 == 0;
+    // dW: the column tiles of X need not divide N as long as the LAST tile's loads stay inside X's rows (round_up(N, BN) <= ldb:
+    // e.g. the actor's 88 -> 96 inputs read from a 128-float-wide tile); whatever those extra columns hold only reaches accumulator
+    // columns >= N, which the (masked) epilogue of a partial tile never stores.  Round 4: the actor's layer-1 dW product had been the
+    // one backward GEMM left on the register-staged loop.
+    else dma = dma && pqlk_round_up(p.N, BN) <= p.ldb && p.rows_per_split % (4 * KT) == 0 && p.K % p.rows_per_split == 0 &&
+               p.K / p.rows_per_split == p.splits && p.M <= p.lda && p.N <= p.ldb && p.sA % 4 == 0 && p.sB % 4 == 0;
     return dma;
   }
   return false;
