@@ -380,7 +380,13 @@ class PQLVLearner:
         dev, f = self.device, dict(dtype=torch.float32, device=self.device)
         O, A = self.memory.ring.O, self.action_dim
         cl, al = self.critic.layout, self.actor.layout
-        ws = dict(B=B, ld_sa=L.ld(O + A), ld_o=L.ld(O))
+        # leading dimension of the critic's input tiles: ld(O + A), and beyond 128 floats a multiple of 128, so that the layer-1 dW
+        # product (X = these tiles) can read whole 128-column tiles of them on the LDS-DMA loop even when ld(O + A) is not a multiple of
+        # the tile (Humanoid: 129 inputs -> ld 160 -> tiles 256 wide; the extra columns are never written and stay zero)
+        ld_sa = L.ld(O + A)
+        if ld_sa > 128:
+            ld_sa = (ld_sa + 127) // 128 * 128
+        ws = dict(B=B, ld_sa=ld_sa, ld_o=L.ld(O))
         # Draws and gathered input tiles of the next K steps (K = 1 without the fused draws): `x_sa` / `xn_sa` / `rew` / `done`
         # are slot 0, the tiles of the per-step path.  cfg #2: K = 8 -> 2 x 33.5 MB of tiles.
         want = self._want_ahead(B)

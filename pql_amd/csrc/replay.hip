@@ -517,7 +517,8 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
   int64_t blocks = (b + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
   if (blocks > 2048) blocks = 2048;
   // aligned transition-ring shape -> lean kernel (pads: at most 64 16-B chunks in total, one lane each)
-  const bool fast = L.A >= 0 && nchunk <= 128 && (ld_sa - L.O - L.A) <= 64 && (!xn_obs || (ld_o - L.O) <= 64) &&
+  // (the pad-column bound only matters when this call has to zero the pads: one lane per pad chunk)
+  const bool fast = L.A >= 0 && nchunk <= 128 && (!write_pads || ((ld_sa - L.O - L.A) <= 64 && (!xn_obs || (ld_o - L.O) <= 64))) &&
                     pqlk_aligned16(x_sa) && pqlk_aligned16(xn_sa) && pqlk_aligned16(xn_obs);
   if (fast) {
     // rows in flight per wave: 2 up to 16 Ki rows (more waves, shorter dependent idx -> row chain: 9.3 vs 10.5 us at 8192),
