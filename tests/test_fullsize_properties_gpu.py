@@ -69,6 +69,58 @@ def test_replay_round_trip_full_ring(dev, cap, O, A, B):
     assert torch.all(x_sa[:, O + A:] == 0) and torch.all(xn_o[:, O:] == 0)
 
 
+def test_replay_round_trip_hbm_scale_ring(dev):
+    """cfg #5's record (1 KiB) in a ring that takes most of the card's HBM (up to 200 M rows = 205 GB; BASELINE configs[4] calls
+    itself a 288-GB buffer stress): insert -> gather is the identity on rows placed around every power-of-two byte boundary
+    from 2^32 up, at the very end of the ring and across the wrap, through the plain and the fused K-batch gather.  Only the rows
+    checked are written -- the property is the 64-bit addressing, not the fill."""
+    from pql_amd import _lib as L
+    from pql_amd.replay.simple_replay import ReplayBuffer
+    O, A = 108, 21
+    rec_bytes = int(L.lib.pqlk_replay_rec_ld(O, A)) * 4
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info(dev)
+    cap = min(200_000_000, int(free * 0.75) // rec_bytes)
+    if cap * rec_bytes < 2 ** 36:
+        pytest.skip(f"only {free / 2 ** 30:.0f} GiB free on the card")
+    rb = ReplayBuffer(cap, (O,), A, device=dev)
+    assert rb.ring.rec_ld * 4 == rec_bytes and rb.ring.records.numel() * 4 == cap * rec_bytes
+    n = 4096
+    starts = [0]
+    e = 32
+    while 2 ** e < cap * rec_bytes:
+        starts.append(2 ** e // rec_bytes - n // 2)   # rows either side of the 2^e-byte boundary
+        e += 1
+    starts.append(cap - n // 2)                       # the last rows + a wrap to the head (overwrites half of the first block)
+    def rows_of(lo):
+        idx = torch.arange(lo, lo + n, device=dev)
+        return idx, (_rows(idx, O, 1), _rows(idx, A, 2), _rows(idx, 1, 3), _rows(idx, O, 4), (_rows(idx, 1, 5) > 0.8).float())
+    for lo in starts:
+        rb.next_p = lo                                # (public state of the reference's class too: simple_replay.py:29-31)
+        rb.add_to_buffer(rows_of(lo)[1])
+    assert rb.if_full and rb.next_p == n // 2 and rb.cur_capacity == cap
+    slots = torch.cat([torch.arange(lo, lo + n, device=dev) % cap for lo in starts[1:]] + [torch.arange(n // 2, n, device=dev)])
+    gr = torch.where(slots < n // 2, slots + cap, slots)   # global row a slot holds (the wrapped head carries rows cap .. cap + n/2)
+    assert int(slots.max()) * rec_bytes > 2 ** 36
+    obs, act, rew, nobs, done = rb.sample_batch(slots.numel(), indices=slots)
+    assert torch.equal(obs, _rows(gr, O, 1)) and torch.equal(act, _rows(gr, A, 2)) and torch.equal(nobs, _rows(gr, O, 4))
+    assert torch.equal(rew, _rows(gr, 1, 3)) and torch.equal(done, (_rows(gr, 1, 5) > 0.8).float())
+    # the learners' launch: fused gather (fast path: flags 3), identity normalisation
+    B = slots.numel()
+    ld_sa = L.ld(O + A)
+    f = dict(dtype=torch.float32, device=dev)
+    x_sa, xn_sa = torch.zeros((B, ld_sa), **f), torch.zeros((B, ld_sa), **f)
+    r2, d2 = torch.empty(B, **f), torch.empty(B, **f)
+    mean, var = torch.zeros(O, **f), torch.full((O,), 1.0 - 2.0 ** -13, **f)
+    perm = torch.randperm(B, device=dev)
+    L.check(L.lib.pqlk_replay_gather_fused(C.byref(rb.ring.desc), L.ptr(slots[perm].contiguous()), B, L.ptr(mean), L.ptr(var), 2.0 ** -13, 3,
+                                           L.ptr(x_sa), ld_sa, L.ptr(xn_sa), None, 0, L.ptr(r2), L.ptr(d2), L.stream(dev)))
+    assert torch.equal(x_sa[:, :O], obs[perm]) and torch.equal(x_sa[:, O:O + A], act[perm]) and torch.equal(xn_sa[:, :O], nobs[perm])
+    assert torch.equal(r2, rew.view(-1)[perm]) and torch.equal(d2, done.view(-1)[perm])
+    del rb, x_sa, xn_sa
+    torch.cuda.empty_cache()
+
+
 def test_nstep_properties_cfg4_shape(dev):
     """16384 envs x obs 211 (cfg #4), n = 3: with no dones the emitted transition is (obs_t, act_t, sum gamma^j r_{t+j},
     next_obs_{t+2}, 0); a done in the window truncates the return there, selects that step's next_obs and raises done;

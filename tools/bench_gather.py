@@ -5,7 +5,9 @@ hooks of the flag word.  Two timings per point (HIP events around hipGraph repla
   iso  -- ONE launch at a time behind a 384-MB eviction write, rotating output-tile sets (bench.isolated_launch_ms: what the
           schedule pays, and what rocprofv3's per-launch durations show)
 GPU only.
-    python tools/bench_gather.py [cfg2|cfg5|cfg4|cfg2x8|cfg5x8|cfg4x8|p2|p2x4] ... [--quick]"""
+    python tools/bench_gather.py [cfg2|cfg5|cfg4|cfg2x8|cfg5x8|cfg4x8|p2|p2x4] ... [--quick] [--auto]
+A name may carry a ring size, `cfg5x8@150M` (rows; the 1-KiB records of cfg #5 x 150 M = 154 GB): the same launch over a ring that
+takes most of the card.  --auto: only the learner's own flag word (no sweep)."""
 import ctypes as C
 import os
 import sys
@@ -22,14 +24,18 @@ from pql_amd.replay.simple_replay import RecordRing, ReplayBuffer  # noqa: E402
 CFG = {"cfg2": (88, 16, 8192, 1_000_000), "cfg5": (108, 21, 32768, 5_000_000), "cfg4": (211, 20, 8192, 2_000_000),
        "cfg2x8": (88, 16, 8 * 8192, 1_000_000), "cfg5x8": (108, 21, 8 * 32768, 5_000_000), "cfg4x8": (211, 20, 8 * 8192, 2_000_000),
        "p2": (88, -1, 8192, 1_000_000), "p2x4": (88, -1, 4 * 8192, 1_000_000), "p4x4": (211, -1, 4 * 8192, 2_000_000),
+       "p5x4": (108, -1, 4 * 32768, 5_000_000),
        # "...s": the obs ring gathered into ONE destination (the actor's input tile: what the P-learner does since round 4)
        "p2s": (88, -1, 8192, 1_000_000), "p2x4s": (88, -1, 4 * 8192, 1_000_000)}
 SETS, N_ISO = 4, 16
 
 
-def run(name, quick=False, iters=30):
+def run(name, quick=False, iters=30, auto=False):
+    name, _, rows = name.partition("@")
     iters = max(4, min(iters, (1 << 23) // CFG[name][2]))   # (bound the index tensor for the 8-batch launches)
     O, A, B, cap = CFG[name]
+    if rows:
+        cap = int(float(rows.rstrip("Mk")) * {"M": 1e6, "k": 1e3}.get(rows[-1], 1))
     dev = torch.device("cuda:0")
     obs_only = A < 0
     if obs_only:
@@ -38,7 +44,10 @@ def run(name, quick=False, iters=30):
         rb = ReplayBuffer(cap, (O,), A, dev)
         rb.cur_capacity, rb.if_full = cap, True
         ring = rb.ring
-    ring.records.normal_()
+    if cap * ring.rec_ld * 4 < (8 << 30):
+        ring.records.normal_()
+    else:   # (values do not matter to the timing; a 100-GB normal_ is 25 G Philox draws)
+        ring.records.fill_(0.25)
     ld_sa, ld_o = L.ld(O + max(A, 16)), L.ld(O)
     f = dict(dtype=torch.float32, device=dev)
     single = name.endswith("s")
@@ -78,7 +87,8 @@ def run(name, quick=False, iters=30):
         return isolated_launch_ms(lambda i, s: one(i, s, norm, flags), dev, N_ISO, SETS) * 1e3
 
     print(f"== {name}: O={O} A={A} B={B} rec={ring.rec_ld * 4}B  algorithmic {alg / 1e6:.2f} MB, moved {real / 1e6:.2f} MB", flush=True)
-    Rs = (1, 2, 4) if obs_only else (2, 4)
+    print(f"  ring {cap} rows = {cap * ring.rec_ld * 4 / 1e9:.1f} GB", flush=True)
+    Rs = () if auto else (1, 2, 4) if obs_only else (2, 4)
     wpcs = (8, 16, 24, 32) if obs_only else (8, 12, 16, 24, 32)
     if quick:
         wpcs = (12, 16, 24) if not obs_only else (8, 16, 32)
@@ -98,4 +108,5 @@ def run(name, quick=False, iters=30):
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     for n in (args or ["cfg2", "cfg5"]):
-        run(n, quick="--quick" in sys.argv)
+        run(n, quick="--quick" in sys.argv, auto="--auto" in sys.argv)
+        torch.cuda.empty_cache()
