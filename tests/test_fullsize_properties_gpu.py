@@ -84,6 +84,15 @@ def test_replay_round_trip_hbm_scale_ring(dev):
     if cap * rec_bytes < 2 ** 36:
         pytest.skip(f"only {free / 2 ** 30:.0f} GiB free on the card")
     rb = ReplayBuffer(cap, (O,), A, device=dev)
+    try:
+        _hbm_scale_body(rb, cap, rec_bytes, O, A, dev)
+    finally:   # give the 200 GB back even when an assertion keeps this frame alive in a traceback
+        rb.ring.records.untyped_storage().resize_(0)
+        torch.cuda.empty_cache()
+
+
+def _hbm_scale_body(rb, cap, rec_bytes, O, A, dev):
+    from pql_amd import _lib as L
     assert rb.ring.rec_ld * 4 == rec_bytes and rb.ring.records.numel() * 4 == cap * rec_bytes
     n = 4096
     starts = [0]
@@ -117,8 +126,6 @@ def test_replay_round_trip_hbm_scale_ring(dev):
                                            L.ptr(x_sa), ld_sa, L.ptr(xn_sa), None, 0, L.ptr(r2), L.ptr(d2), L.stream(dev)))
     assert torch.equal(x_sa[:, :O], obs[perm]) and torch.equal(x_sa[:, O:O + A], act[perm]) and torch.equal(xn_sa[:, :O], nobs[perm])
     assert torch.equal(r2, rew.view(-1)[perm]) and torch.equal(d2, done.view(-1)[perm])
-    del rb, x_sa, xn_sa
-    torch.cuda.empty_cache()
 
 
 def test_nstep_properties_cfg4_shape(dev):

@@ -55,6 +55,43 @@ def test_ring_insert_and_sample(golden, dev, name):
     assert torch.equal(rb.draw_indices(16), expect)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_ring_random_insert_sequences_vs_oracle(dev, ref, seed):
+    """Seeded random rings (capacity, widths) and insert sequences -- single rows, exact fills, inserts of the whole capacity,
+    several wraps -- against the oracle's ring: pointer state after every insert, the five field views and a gather that names every
+    slot, all bit for bit; the P-learner's obs-only ring runs the same sequence."""
+    from pql_amd import _lib as L
+    from pql_amd.replay.simple_replay import RecordRing, ReplayBuffer, ring_plan
+    rs = np.random.RandomState(1000 + seed)
+    cap = int(rs.choice([1, 2, 7, 32, 33, 100, 257]))
+    O, A = int(rs.choice([1, 3, 8, 13, 33])), int(rs.choice([1, 2, 5, 17]))
+    rb, oracle = ReplayBuffer(cap, (O,), A, device=dev), ref.RingRef(cap, O, A)
+    pr, poracle = RecordRing(cap, O, -1, dev), ref.ObsRingRef(cap, O)   # (the P-learner keeps the pointer state itself)
+    p_next, p_full, p_cur = 0, False, 0
+    for step in range(14):
+        m = int(rs.choice([1, cap, max(1, cap // 2), int(rs.randint(1, cap + 1)), max(1, cap - 1)]))
+        sd = 5000 + 100 * seed + step
+        traj = (T(dd.uniform((m, O), sd)), T(dd.uniform((m, A), sd + 20)), T(dd.uniform((m, 1), sd + 40)), T(dd.uniform((m, O), sd + 60)),
+                T(dd.bernoulli((m, 1), sd + 80, 0.3)))
+        oracle.insert(*traj); poracle.insert(traj[0])
+        rb.add_to_buffer(tuple(t.to(dev) for t in traj))
+        segs, p_next, p_full, p_cur = ring_plan(p_next, p_full, cap, m)
+        pr.insert_segments(segs, traj[0].to(dev))
+        assert (rb.next_p, rb.cur_capacity, rb.if_full) == (oracle.next_p, oracle.cur_capacity, oracle.if_full), step
+        assert (p_next, p_cur, p_full) == (poracle.next_p, poracle.cur_capacity, poracle.if_full), step
+    for mine, want in ((rb.buf_obs, oracle.obs), (rb.buf_action, oracle.act), (rb.buf_reward, oracle.rew), (rb.buf_next_obs, oracle.nobs),
+                       (rb.buf_done, oracle.done)):
+        assert np.array_equal(mine.cpu().numpy(), want.numpy())
+    idx = torch.from_numpy(np.concatenate([np.arange(cap), rs.randint(0, cap, size=50)])).to(torch.int64)
+    for mine, want in zip(rb.sample_batch(idx.numel(), device=dev, indices=idx), oracle.gather(idx)):
+        assert mine.dtype == torch.float32 and np.array_equal(mine.cpu().numpy(), want.numpy())
+    x_o = torch.full((idx.numel(), L.ld(O)), 7.0, device=dev)
+    idx_d = idx.to(dev)
+    L.check(L.lib.pqlk_replay_gather_fused(C.byref(pr.desc), L.ptr(idx_d), idx.numel(), None, None, 0.0, 1, None, 0, None, L.ptr(x_o),
+                                           x_o.stride(0), None, None, L.stream(dev)))
+    assert np.array_equal(x_o[:, :O].cpu().numpy(), poracle.gather(idx).numpy()) and torch.all(x_o[:, O:] == 0)
+
+
 def test_ring_rejects_cpu_and_oversize(dev):
     from pql_amd._lib import PqlkError
     from pql_amd.replay.simple_replay import ReplayBuffer
@@ -228,6 +265,30 @@ def test_nstep_large_vs_oracle(dev, ref):
         exp = orc.add(*args)
         for a, b in zip(got, exp):
             assert torch.equal(a.cpu(), b)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_nstep_random_call_sequences_vs_oracle(dev, ref, seed):
+    """Seeded random (envs, n, widths, gamma) and call sequences -- a first call of at least n steps, then calls of 1 .. 2n steps,
+    dense and sparse dones -- against the oracle's per-window restatement of nstep_replay.py:74-92: every emitted row bit for bit
+    (incl. the fp32 order of the discounted reward sum)."""
+    from pql_amd.replay.nstep_replay import NStepReplay
+    rs = np.random.RandomState(2000 + seed)
+    N, n = int(rs.choice([1, 5, 64, 257])), int(rs.choice([1, 2, 3, 5, 7]))
+    O, A = int(rs.choice([1, 4, 13])), int(rs.choice([1, 3, 6]))
+    gamma = float(rs.choice([0.99, 0.9, 1.0]))
+    ns = NStepReplay((O,), A, N, n, gamma=gamma, device=dev)
+    orc = ref.NStepRef(O, A, N, n, gamma=gamma)
+    p_done = float(rs.choice([0.02, 0.3, 0.9]))
+    for ci in range(6):
+        Tn = int(rs.randint(n, 3 * n + 1)) if ci == 0 else int(rs.randint(1, 2 * n + 1))
+        s = 7000 + 100 * seed + 10 * ci
+        args = [T(dd.uniform((N, Tn, O), s)), T(dd.uniform((N, Tn, A), s + 1)), T(dd.uniform((N, Tn, 1), s + 2, -2, 2)),
+                T(dd.uniform((N, Tn, O), s + 3)), T(dd.bernoulli((N, Tn, 1), s + 4, p_done))]
+        got = ns.add_to_buffer(*(a.to(dev) for a in args))
+        exp = orc.add(*args)
+        for nm, a, b in zip(("obs", "act", "rew", "nobs", "done"), got, exp):
+            assert a.shape == b.shape and torch.equal(a.cpu(), b), (ci, nm)
 
 
 # --------------------------------------------------------------------------- MLP family vs golden
