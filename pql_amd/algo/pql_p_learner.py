@@ -25,6 +25,7 @@ from pql_amd.models import model_name_to_path
 from pql_amd.models.mlp import PackedWeights, default_splits, mlp_forward_raw, output_view
 from pql_amd.replay.simple_replay import RecordRing, _obs_width, ring_plan
 from pql_amd.utils import handoff as H
+from pql_amd.utils.dp import drain_pending_collectives
 from pql_amd.utils import rng as R
 from pql_amd.utils.common import Tracker, load_class_from_path
 
@@ -409,6 +410,8 @@ class PQLPLearner:
             dst.copy_(src)
         self.repack()
         g = self._new_graph()
+        if self.dp:   # (a run graph under data parallel exists only with captured collectives)
+            drain_pending_collectives(self.pg)
         with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
             run()
         for dst, src in zip(self._state(), snap):
@@ -484,6 +487,8 @@ class PQLPLearner:
         # PQL_DP_GRAPH_COLLECTIVE=1 (opt-in, RCCL only, rehearsed with a 1-rank group only): capture the all-reduce inside
         # ONE graph instead of splitting the step around an eager collective
         if not self.dp or graph_collective_enabled(self.pg):
+            if self.dp:
+                drain_pending_collectives(self.pg)   # (the warm-up's eager all-reduce must have left the watchdog's list)
             with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
                 step(draw=self._graph_rng)
         else:

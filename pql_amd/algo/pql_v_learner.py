@@ -714,6 +714,8 @@ class PQLVLearner:
         torch.cuda.current_stream(self.device).wait_stream(s)
         self._restore(snap)
         g = self._new_graph()
+        if self.dp:   # (a run graph under data parallel exists only with captured collectives)
+            DP.drain_pending_collectives(self.pg)
         with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
             run()
         self._restore(snap)
@@ -790,6 +792,8 @@ class PQLVLearner:
         # PQL_DP_GRAPH_COLLECTIVE=1 (opt-in, RCCL only, rehearsed with a 1-rank group only): capture the all-reduce inside
         # ONE graph instead of splitting the step around an eager collective
         if not self.dp or graph_collective_enabled(self.pg):
+            if self.dp:
+                DP.drain_pending_collectives(self.pg)   # (the warm-up's eager all-reduce must have left the watchdog's list)
             with torch.cuda.graph(g, stream=self._capture_stream, capture_error_mode="thread_local"):
                 step(draw=self._graph_rng)
         else:   # two graphs around the RCCL all-reduce (kept eager: no collective is ever captured)

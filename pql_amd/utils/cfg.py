@@ -3,7 +3,8 @@
 The reference composes its config with Hydra 1.x (`@hydra.main(config_path=pql/cfg, config_name="default")`,
 scripts/train_pql.py:27).  Hydra/omegaconf are not installed in this image, so this module implements the
 subset the reference uses: `defaults` lists (group: option, `file.yaml` includes, `_self_`), relative
-interpolation `${.key}`, and command-line overrides `a.b=value` / `group=option`.  The result is a `Cfg`
+interpolation `${.key}`, and command-line overrides `a.b=value` / `+a.b=value` / `++a.b=value` / `group=option` with Hydra's
+struct-mode rule (overriding a key the composed config lacks is an error, not a new key).  The result is a `Cfg`
 with attribute and item access, accepted everywhere the reference passes a DictConfig.
 """
 from __future__ import annotations
@@ -121,19 +122,28 @@ def load_cfg(overrides=(), config_name="default", cfg_dir: Path = CFG_DIR) -> Cf
     group_choices, assigns = {}, []
     for ov in overrides:
         key, _, val = ov.partition("=")
+        plus = len(key) - len(key.lstrip("+"))   # Hydra: `key=` overrides an existing key, `+key=` adds one, `++key=` does either
         key = key.lstrip("+")
         if key in groups:
             group_choices[key] = _parse_value(val)
         else:
-            assigns.append((key, _parse_value(val)))
+            assigns.append((key, _parse_value(val), plus))
     tree = _load_file(cfg_dir / f"{config_name}.yaml", group_choices)
-    for key, val in assigns:
+    for key, val, plus in assigns:
         cur = tree
         parts = key.split(".")
+        exists = True
         for p in parts[:-1]:
             if not isinstance(cur.get(p), dict):
+                exists = False
                 cur[p] = {}
             cur = cur[p]
+        exists = exists and parts[-1] in cur
+        # a typo in an override must fail at config load, as it does under Hydra's struct mode -- not train a default silently
+        if plus == 0 and not exists:
+            raise KeyError(f"Could not override '{key}': no such key in the composed config.  To add a new key use +{key}={val}")
+        if plus == 1 and exists:
+            raise KeyError(f"Could not append '{key}': the config already has it.  To override it drop the '+', or use ++{key}={val}")
         cur[parts[-1]] = val
     _resolve(tree, tree)
     return _wrap(tree)

@@ -126,6 +126,24 @@ def bucket_views(grads, layout, layer_hi, layer_lo):
     return [grads[n * layout.net_stride + lo: n * layout.net_stride + hi] for n in range(layout.n_nets)]
 
 
+def drain_pending_collectives(pg):
+    """Call before a hipGraph capture that records RCCL collectives of `pg`: returns when the communicator's watchdog thread has
+    retired every eager work.  The capture puts the communicator's internal stream into capture mode, and HIP then refuses
+    hipEventQuery on every event last recorded on that stream -- including the end event of an EAGER collective issued before
+    the capture (the warm-up run), which the watchdog is still polling until its next 100-ms sweep: `operation not permitted on
+    an event last recorded in a capturing stream` then aborts the process (seen once in ~15 runs of the bucket test)."""
+    if pg is None:
+        return
+    wait = getattr(pg, "_wait_for_pending_works", None)
+    if wait is not None:
+        wait()
+    else:   # (older torch: two watchdog sweeps)
+        import time
+        import torch
+        torch.cuda.synchronize()
+        time.sleep(0.25)
+
+
 class BucketAllReduce:
     """Issues the buckets' sum-all-reduces without waiting for them; `wait()` orders the current stream behind all of them
     (and is where the optimiser may start).  RCCL: one grouped launch per bucket (`allreduce_coalesced`: the per-net ranges of

@@ -178,6 +178,21 @@ def _reference_style_eval(cfg, policy, states):
     return {"eval/return": ret_t.mean(), "eval/episode_length": len_t.mean()}
 
 
+def test_override_of_a_missing_key_fails_like_hydra_struct_mode():
+    """A typo in an override must not train a default silently (the reference composes with Hydra, whose struct mode refuses
+    `key=value` for a key the composed config lacks): `key=` overrides, `+key=` adds, `++key=` does either."""
+    from pql_amd.utils.cfg import load_cfg
+    with pytest.raises(KeyError, match="Could not override 'algo.critic.hidden_layers'"):
+        load_cfg(["algo.critic.hidden_layers=[512,512,256]"])
+    with pytest.raises(KeyError, match="Could not override 'algo.update_times'"):   # a DDPG/SAC key, absent from the PQL group
+        load_cfg(["algo.update_times=4"])
+    assert load_cfg(["algo=ddpg_algo", "algo.update_times=4"]).algo.update_times == 4
+    with pytest.raises(KeyError, match="Could not append 'algo.batch_size'"):
+        load_cfg(["+algo.batch_size=64"])
+    cfg = load_cfg(["+algo.my_note=7", "++algo.batch_size=64", "++algo.other.note=x", "algo.hidden_layers=[512,512,256]"])
+    assert (cfg.algo.my_note, cfg.algo.batch_size, cfg.algo.other.note, list(cfg.algo.hidden_layers)) == (7, 64, "x", [512, 512, 256])
+
+
 def test_evaluator_in_process_engine(tmp_path):
     """Cooperative evaluator: same numbers as the reference's rollout loop, results appear after enough polls, the best
     model is kept, and the stop criterion follows evaluator.py:34-38."""
