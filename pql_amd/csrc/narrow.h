@@ -202,6 +202,16 @@ struct SliceHeadX {
   float* part; long long part_floats;
 };
 
+// Profiling hook (tools/probes/slice_phases.sh): -DPQLK_SLICE_SKIP=n builds a library whose k_dx_slice returns after phase n
+// (1 head-operand requests, 2 weight staging, 3 MFMA loop, 4 reduction + dz tile); the difference of two builds' kernel durations is
+// a phase's cost.  `keep` makes what the phase loaded or computed observable so that it is not optimised away.  Never defined
+// in the product build.
+#ifdef PQLK_SLICE_SKIP
+#define PQLK_SLICE_PHASE_END(n, keep) do { if (PQLK_SLICE_SKIP == (n)) { if ((keep) == 1.2345e30f) p.C[0] = 1.f; return; } } while (0)
+#else
+#define PQLK_SLICE_PHASE_END(n, keep) do { } while (0)
+#endif
+
 template <int D, int QPW = 0>   // ring depth; K8 % D == 0
 // (waves_per_eu 2: two blocks per CU -- the 66-KB weight stage allows exactly two -- so at most 256 registers per lane, AGPRs included)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k_dx_slice(GemmP p, SliceHeadX x) {
@@ -250,6 +260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
       }
     }
   }
+  PQLK_SLICE_PHASE_END(1, hxv[0].x + haux[0] + (float)hrow[0]);
   const int ktot = p.groups * p.K;          // p.K = hidden width (multiple of 32)
   const int kq = ktot >> 2;                 // reduction elements of this wave; multiple of 8
   const int kbeg = wave * kq;
@@ -290,6 +301,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
       }
     }
   }
+  PQLK_SLICE_PHASE_END(2, wt[lane] + hxv[0].x + haux[0]);
   // the wave reads only what it staged itself: no block barrier needed before the loop (LDS ops of a wave are in order)
   const int row = min(m0 + r, p.M - 1);
   const int g0 = kbeg / p.K, koff = kbeg - g0 * p.K;   // a wave's quarter lies inside one net when n_nets divides 4
@@ -317,6 +329,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
       __builtin_amdgcn_sched_barrier(0);   // keep the refill here (see k_fwd_narrow)
     }
   }
+  PQLK_SLICE_PHASE_END(3, acc4[0][0] + acc4[1][1] + acc4[2][2] + acc4[3][3] + hxv[0].x + haux[0]);
   // partial tiles -> LDS (reusing the staging area after everyone is done with it), summed in wave order by wave 0
   __syncthreads();
   float* red = dxs_lds;   // [wave][reg][lane]
@@ -377,6 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void k
     }
   }
   __syncthreads();
+  PQLK_SLICE_PHASE_END(4, dzt[tid & 511] + hxv[0].x);
   if (QPW > 0) {
     constexpr int Q = HQ, RPL = HRPL;
     const int qg = lane % Q, rg = lane / Q;
