@@ -240,6 +240,17 @@ __global__ __launch_bounds__(256) void k_replay_gather_fused(const float* __rest
   }
 }
 
+// (x - mean) / sd with the division as ONE double-precision product rounded once to fp32 -- bit for bit the IEEE quotient the
+// reference's `(x - mean) / sqrt(var + eps)` rounds to (common.py:139-145), in 3 instructions per element instead of the 12 of the
+// fp32 division sequence (v_div_scale x2, v_rcp, 6 FMAs / multiplies, v_div_fmas, v_div_fixup): the gather kernels spent ~100 VALU
+// instructions per record on four divisions.  rd = 1 / (double)sd is formed once per lane (correctly rounded: relative error
+// <= 2^-53), the product adds <= 2^-53, so the double result is within 2^-51.9 (relative) of a / sd.  The exact quotient of two
+// fp32 numbers is never that close to a boundary between two fp32 results: a boundary m has <= 25 significant bits, a - m sd != 0
+// is a multiple of ulp(m) ulp(sd), which puts |a / sd - m| / |a / sd| above 2^-49 (normal and denormal results alike; the overflow
+// threshold is one more such boundary).  Signed zeros, infinities and NaN come out as IEEE division gives them (a * (1 / inf) =
+// a * 0).  tests: the gather tests are bit-exact against the oracle's fp32 division; test_gather_division_is_the_ieee_quotient.
+__device__ __forceinline__ float norm_div(float a, double rd) { return (float)((double)a * rd); }
+
 // Fast path for transition rings whose record fits one 16-B chunk per lane (<= 1 KiB used, e.g. cfg #2 and #5): the field
 // decode, destination and normalisation constants of a lane depend only on its chunk index, so they are computed ONCE
 // per kernel and the per-row work is load -> (sub, IEEE div, clamp) x4 -> one or two 16-B stores.  The generic kernel
@@ -287,12 +298,14 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
   }
   vecA = vecA && nvalid == 4;
   float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  double rd[4] = {1.0, 1.0, 1.0, 1.0};   // 1 / sd (norm_div)
   const bool do_norm = HAS_NORM && ncol >= 0;
+  const bool ieee_div = (nt_loads & 4) != 0;   // A/B switch (PQLK_GATHER_IEEE_DIV): the fp32 division sequence
   if (do_norm) {   // scalar loads: O need not be a multiple of 4; invalid tail elements keep (0, 1)
     float mm[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (j < nvalid) { mm[j] = mean[ncol + j]; ss[j] = sqrtf(var[ncol + j] + eps); }
+      if (j < nvalid) { mm[j] = mean[ncol + j]; ss[j] = sqrtf(var[ncol + j] + eps); rd[j] = 1.0 / (double)ss[j]; }
     m4 = make_float4(mm[0], mm[1], mm[2], mm[3]);
     s4 = make_float4(ss[0], ss[1], ss[2], ss[3]);
   }
@@ -344,7 +357,12 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
       if (r >= b) break;
       float4 x = v[i];
       if (do_norm) {
-        x.x = (x.x - m4.x) / s4.x; x.y = (x.y - m4.y) / s4.y; x.z = (x.z - m4.z) / s4.z; x.w = (x.w - m4.w) / s4.w;
+        if (ieee_div) {   // (wave-uniform)
+          x.x = (x.x - m4.x) / s4.x; x.y = (x.y - m4.y) / s4.y; x.z = (x.z - m4.z) / s4.z; x.w = (x.w - m4.w) / s4.w;
+        } else {
+          x.x = norm_div(x.x - m4.x, rd[0]); x.y = norm_div(x.y - m4.y, rd[1]);
+          x.z = norm_div(x.z - m4.z, rd[2]); x.w = norm_div(x.w - m4.w, rd[3]);
+        }
         if (clamp5) {
           x.x = fminf(fmaxf(x.x, -5.f), 5.f); x.y = fminf(fmaxf(x.y, -5.f), 5.f);
           x.z = fminf(fmaxf(x.z, -5.f), 5.f); x.w = fminf(fmaxf(x.w, -5.f), 5.f);
@@ -403,7 +421,8 @@ __global__ __launch_bounds__(256) void k_replay_gather_obs(const float* __restri
                                                            const int64_t* __restrict__ idx, int64_t b,
                                                            const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                                            int clamp5, float* __restrict__ x_sa, int64_t ld_sa,
-                                                           float* __restrict__ x_obs, int64_t ld_o, int write_pads, int lgp) {
+                                                           float* __restrict__ x_obs, int64_t ld_o, int write_pads, int lgp,
+                                                           int ieee_div) {
   const int lane = threadIdx.x & 63;
   const int P = 1 << lgp, G = 64 >> lgp;
   const int grp = lane >> lgp, cl = lane & (P - 1);   // record of the instruction, chunk of the record
@@ -412,11 +431,12 @@ __global__ __launch_bounds__(256) void k_replay_gather_obs(const float* __restri
   const bool active = cl < nchunk;
   const int nvalid = active ? min(4, L.O - c) : 0;   // < 4 only in the last chunk when O is not a multiple of 4
   float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  double rd[4] = {1.0, 1.0, 1.0, 1.0};   // 1 / sd (norm_div)
   if (HAS_NORM && active) {
     float mm[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (j < nvalid) { mm[j] = mean[c + j]; ss[j] = sqrtf(var[c + j] + eps); }
+      if (j < nvalid) { mm[j] = mean[c + j]; ss[j] = sqrtf(var[c + j] + eps); rd[j] = 1.0 / (double)ss[j]; }
     m4 = make_float4(mm[0], mm[1], mm[2], mm[3]);
     s4 = make_float4(ss[0], ss[1], ss[2], ss[3]);
   }
@@ -451,7 +471,12 @@ __global__ __launch_bounds__(256) void k_replay_gather_obs(const float* __restri
       if (r >= b) continue;
       float4 x = v[i];
       if (HAS_NORM) {
-        x.x = (x.x - m4.x) / s4.x; x.y = (x.y - m4.y) / s4.y; x.z = (x.z - m4.z) / s4.z; x.w = (x.w - m4.w) / s4.w;
+        if (ieee_div) {   // (wave-uniform A/B switch)
+          x.x = (x.x - m4.x) / s4.x; x.y = (x.y - m4.y) / s4.y; x.z = (x.z - m4.z) / s4.z; x.w = (x.w - m4.w) / s4.w;
+        } else {
+          x.x = norm_div(x.x - m4.x, rd[0]); x.y = norm_div(x.y - m4.y, rd[1]);
+          x.z = norm_div(x.z - m4.z, rd[2]); x.w = norm_div(x.w - m4.w, rd[3]);
+        }
         if (clamp5) {
           x.x = fminf(fmaxf(x.x, -5.f), 5.f); x.y = fminf(fmaxf(x.y, -5.f), 5.f);
           x.z = fminf(fmaxf(x.z, -5.f), 5.f); x.w = fminf(fmaxf(x.w, -5.f), 5.f);
@@ -500,7 +525,7 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
   const int clamp5 = flags & PQLK_GATHER_CLAMP5;
   const int write_pads = (flags & PQLK_GATHER_PADS_ZERO) ? 0 : 1;
   const int tune_R = (flags >> 8) & 15, tune_wpc = (flags >> 12) & 63;
-  int nt_loads = ((flags & PQLK_GATHER_NT_LOADS) ? 1 : 0) | ((flags & PQLK_GATHER_NT_STORES) ? 2 : 0);
+  int nt_loads = ((flags & PQLK_GATHER_NT_LOADS) ? 1 : 0) | ((flags & PQLK_GATHER_NT_STORES) ? 2 : 0) | ((flags & PQLK_GATHER_IEEE_DIV) ? 4 : 0);
   PQLK_REQUIRE(ring && ring->records && idx, PQLK_E_NULL);
   PQLK_REQUIRE(ring->obs_dim > 0 && ring->capacity > 0 && b >= 0, PQLK_E_SHAPE);
   RecLayout L = rec_layout(ring->obs_dim, ring->act_dim);
@@ -580,7 +605,7 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
     const dim3 g((unsigned)fb), t(256);
 #define PQLK_GATHER_OBS(NORM, RR) \
     hipLaunchKernelGGL((k_replay_gather_obs<NORM, RR>), g, t, 0, pqlk_s(stream), ring->records, L, ring->capacity, idx, b, mean, var, eps, \
-                       clamp5, x_sa, ld_sa, xn_obs, ld_o, write_pads, lgp)
+                       clamp5, x_sa, ld_sa, xn_obs, ld_o, write_pads, lgp, nt_loads & 4)
 #define PQLK_GATHER_OBS_R(NORM) \
     do { if (R == 1) PQLK_GATHER_OBS(NORM, 1); else if (R == 2) PQLK_GATHER_OBS(NORM, 2); else PQLK_GATHER_OBS(NORM, 4); } while (0)
     if (mean) PQLK_GATHER_OBS_R(true); else PQLK_GATHER_OBS_R(false);

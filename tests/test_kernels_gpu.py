@@ -165,6 +165,57 @@ def test_gather_pads_zero_flag_and_multi_trip_grid(dev, ref, O, A):
         assert torch.equal(rew.cpu(), r.view(-1)) and torch.equal(done.cpu(), d.view(-1))
 
 
+@pytest.mark.parametrize("obs_only", [False, True])
+def test_gather_division_is_the_ieee_quotient(dev, obs_only):
+    """The gather kernels normalise with ONE double-precision product per element (replay.hip: norm_div) instead of the fp32
+    division sequence; it must be the IEEE quotient bit for bit -- checked here on 35 M arbitrary bit patterns (huge, denormal,
+    signed zeros, infinities, NaN) against torch's fp32 division on the same device and numpy's on the host, for standard deviations
+    spread over 12 decades and packed around 1; the PQLK_GATHER_IEEE_DIV build of the same launch must agree too."""
+    from pql_amd import _lib as L
+    from pql_amd.replay.simple_replay import RecordRing, ReplayBuffer
+    O, A, cap = 88, 16, 200_000
+    g = torch.Generator(device=dev).manual_seed(17)
+    bits = torch.randint(-2 ** 31, 2 ** 31, (cap, O), device=dev, generator=g, dtype=torch.int64).to(torch.int32)
+    obs = bits.view(torch.float32).clone()
+    obs[::5] = torch.randn((obs[::5].shape), device=dev, generator=g) * 3                 # ordinary observations
+    obs[1::97, :8] = torch.tensor([0.0, -0.0, float("inf"), -float("inf"), float("nan"), 1e-45, -1e-45, 3.4e38], device=dev)
+    nobs = obs.flip(0).contiguous()
+    if obs_only:
+        ring = RecordRing(cap, O, -1, dev)
+        ring.insert_segments([(0, 0, cap)], obs)
+    else:
+        rb = ReplayBuffer(cap, (O,), A, device=dev)
+        rb.add_to_buffer((obs, torch.zeros((cap, A), device=dev), torch.zeros((cap, 1), device=dev), nobs, torch.zeros((cap, 1), device=dev)))
+        ring = rb.ring
+    assert torch.equal(ring.records[:, :O].view(torch.int32), obs.view(torch.int32))   # the ring holds the bit patterns untouched
+    mean = torch.zeros(O, device=dev)                      # x - 0 = x exactly (and -0 - 0 = -0): the division sees the raw patterns
+    sd_exp = torch.linspace(-6, 6, O, device=dev)
+    var = (10.0 ** sd_exp) ** 2
+    var[::3] = (1.0 + torch.rand(var[::3].shape, device=dev, generator=g)) ** 2
+    eps = 1e-4
+    sd = torch.sqrt(var + eps)
+    idx = torch.randperm(cap, device=dev, generator=g)
+    ld_sa, ld_o = L.ld(O + max(A, 0)), L.ld(O)
+    outs = {}
+    for name, flags in (("product", 0), ("ieee", 16)):
+        x_sa = torch.zeros((cap, ld_sa), device=dev); xn_sa = torch.zeros((cap, ld_sa), device=dev); x_o = torch.zeros((cap, ld_o), device=dev)
+        L.check(L.lib.pqlk_replay_gather_fused(C.byref(ring.desc), L.ptr(idx), cap, L.ptr(mean), L.ptr(var), eps, flags, L.ptr(x_sa), ld_sa,
+                                               None if obs_only else L.ptr(xn_sa), L.ptr(x_o), ld_o, None, None, L.stream(dev)))
+        outs[name] = (x_sa[:, :O].clone(), (x_o if obs_only else xn_sa)[:, :O].clone())
+    want = ((obs - mean) / sd)[idx], ((obs if obs_only else nobs) / sd)[idx]
+
+    def same_bits(a, b):
+        both_nan = torch.isnan(a) & torch.isnan(b)
+        return bool(torch.all((a.view(torch.int32) == b.view(torch.int32)) | both_nan))
+    for k in (0, 1):
+        assert same_bits(outs["product"][k], want[k]), ("product vs torch division", k)
+        assert same_bits(outs["ieee"][k], want[k]), ("ieee vs torch division", k)
+    with np.errstate(all="ignore"):
+        host = (obs[idx][:4096].cpu().numpy() / sd.cpu().numpy()).astype(np.float32)   # numpy on the host: IEEE by construction
+    got = outs["product"][0][:4096].cpu().numpy()
+    assert np.array_equal(got.view(np.uint32)[~np.isnan(host)], host.view(np.uint32)[~np.isnan(host)]) and np.isnan(got[np.isnan(host)]).all()
+
+
 def test_obs_ring_gather(dev, ref):
     from pql_amd import _lib as L
     from pql_amd.replay.simple_replay import RecordRing, ring_plan
