@@ -110,7 +110,6 @@ int pqlk_replay_gather(const PqlReplayDesc* ring, const int64_t* idx, int64_t b,
 #define PQLK_GATHER_PADS_ZERO 2
 #define PQLK_GATHER_NT_LOADS 4
 #define PQLK_GATHER_NT_STORES 8   /* experiment: non-temporal stores of the main 16-B tile writes */
-#define PQLK_GATHER_IEEE_DIV 16  /* A/B: the fp32 division sequence instead of the (bit-identical) double-precision product */
 #define PQLK_GATHER_ROWS_IN_FLIGHT(r) (((r) & 15) << 8)
 #define PQLK_GATHER_WAVES_PER_CU(w) (((w) & 63) << 12)
 int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t* idx, int64_t b,

@@ -297,17 +297,15 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
     }
   }
   vecA = vecA && nvalid == 4;
-  float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
   double rd[4] = {1.0, 1.0, 1.0, 1.0};   // 1 / sd (norm_div)
   const bool do_norm = HAS_NORM && ncol >= 0;
-  const bool ieee_div = (nt_loads & 4) != 0;   // A/B switch (PQLK_GATHER_IEEE_DIV): the fp32 division sequence
   if (do_norm) {   // scalar loads: O need not be a multiple of 4; invalid tail elements keep (0, 1)
     float mm[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (j < nvalid) { mm[j] = mean[ncol + j]; ss[j] = sqrtf(var[ncol + j] + eps); rd[j] = 1.0 / (double)ss[j]; }
     m4 = make_float4(mm[0], mm[1], mm[2], mm[3]);
-    s4 = make_float4(ss[0], ss[1], ss[2], ss[3]);
   }
   // pad columns [O+A, ld_sa) of x_sa / xn_sa and [O, ld_o) of xn_obs: lanes take one 16-B zero store each
   // (scalar, <= 31 per matrix: ld - cols < 32 + 3; pads are a few dozen bytes per row)
@@ -357,12 +355,8 @@ __global__ __launch_bounds__(256) void k_replay_gather_fast(const float* __restr
       if (r >= b) break;
       float4 x = v[i];
       if (do_norm) {
-        if (ieee_div) {   // (wave-uniform)
-          x.x = (x.x - m4.x) / s4.x; x.y = (x.y - m4.y) / s4.y; x.z = (x.z - m4.z) / s4.z; x.w = (x.w - m4.w) / s4.w;
-        } else {
-          x.x = norm_div(x.x - m4.x, rd[0]); x.y = norm_div(x.y - m4.y, rd[1]);
-          x.z = norm_div(x.z - m4.z, rd[2]); x.w = norm_div(x.w - m4.w, rd[3]);
-        }
+        x.x = norm_div(x.x - m4.x, rd[0]); x.y = norm_div(x.y - m4.y, rd[1]);
+        x.z = norm_div(x.z - m4.z, rd[2]); x.w = norm_div(x.w - m4.w, rd[3]);
         if (clamp5) {
           x.x = fminf(fmaxf(x.x, -5.f), 5.f); x.y = fminf(fmaxf(x.y, -5.f), 5.f);
           x.z = fminf(fmaxf(x.z, -5.f), 5.f); x.w = fminf(fmaxf(x.w, -5.f), 5.f);
@@ -421,8 +415,7 @@ __global__ __launch_bounds__(256) void k_replay_gather_obs(const float* __restri
                                                            const int64_t* __restrict__ idx, int64_t b,
                                                            const float* __restrict__ mean, const float* __restrict__ var, float eps,
                                                            int clamp5, float* __restrict__ x_sa, int64_t ld_sa,
-                                                           float* __restrict__ x_obs, int64_t ld_o, int write_pads, int lgp,
-                                                           int ieee_div) {
+                                                           float* __restrict__ x_obs, int64_t ld_o, int write_pads, int lgp) {
   const int lane = threadIdx.x & 63;
   const int P = 1 << lgp, G = 64 >> lgp;
   const int grp = lane >> lgp, cl = lane & (P - 1);   // record of the instruction, chunk of the record
@@ -430,7 +423,7 @@ __global__ __launch_bounds__(256) void k_replay_gather_obs(const float* __restri
   const int nchunk = L.used >> 2;
   const bool active = cl < nchunk;
   const int nvalid = active ? min(4, L.O - c) : 0;   // < 4 only in the last chunk when O is not a multiple of 4
-  float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f), s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  float4 m4 = make_float4(0.f, 0.f, 0.f, 0.f);
   double rd[4] = {1.0, 1.0, 1.0, 1.0};   // 1 / sd (norm_div)
   if (HAS_NORM && active) {
     float mm[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {1.f, 1.f, 1.f, 1.f};
@@ -438,7 +431,6 @@ __global__ __launch_bounds__(256) void k_replay_gather_obs(const float* __restri
     for (int j = 0; j < 4; ++j)
       if (j < nvalid) { mm[j] = mean[c + j]; ss[j] = sqrtf(var[c + j] + eps); rd[j] = 1.0 / (double)ss[j]; }
     m4 = make_float4(mm[0], mm[1], mm[2], mm[3]);
-    s4 = make_float4(ss[0], ss[1], ss[2], ss[3]);
   }
   const int64_t rows_trip = (int64_t)R * G;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -471,12 +463,8 @@ __global__ __launch_bounds__(256) void k_replay_gather_obs(const float* __restri
       if (r >= b) continue;
       float4 x = v[i];
       if (HAS_NORM) {
-        if (ieee_div) {   // (wave-uniform A/B switch)
-          x.x = (x.x - m4.x) / s4.x; x.y = (x.y - m4.y) / s4.y; x.z = (x.z - m4.z) / s4.z; x.w = (x.w - m4.w) / s4.w;
-        } else {
-          x.x = norm_div(x.x - m4.x, rd[0]); x.y = norm_div(x.y - m4.y, rd[1]);
-          x.z = norm_div(x.z - m4.z, rd[2]); x.w = norm_div(x.w - m4.w, rd[3]);
-        }
+        x.x = norm_div(x.x - m4.x, rd[0]); x.y = norm_div(x.y - m4.y, rd[1]);
+        x.z = norm_div(x.z - m4.z, rd[2]); x.w = norm_div(x.w - m4.w, rd[3]);
         if (clamp5) {
           x.x = fminf(fmaxf(x.x, -5.f), 5.f); x.y = fminf(fmaxf(x.y, -5.f), 5.f);
           x.z = fminf(fmaxf(x.z, -5.f), 5.f); x.w = fminf(fmaxf(x.w, -5.f), 5.f);
@@ -525,7 +513,7 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
   const int clamp5 = flags & PQLK_GATHER_CLAMP5;
   const int write_pads = (flags & PQLK_GATHER_PADS_ZERO) ? 0 : 1;
   const int tune_R = (flags >> 8) & 15, tune_wpc = (flags >> 12) & 63;
-  int nt_loads = ((flags & PQLK_GATHER_NT_LOADS) ? 1 : 0) | ((flags & PQLK_GATHER_NT_STORES) ? 2 : 0) | ((flags & PQLK_GATHER_IEEE_DIV) ? 4 : 0);
+  int nt_loads = ((flags & PQLK_GATHER_NT_LOADS) ? 1 : 0) | ((flags & PQLK_GATHER_NT_STORES) ? 2 : 0);
   PQLK_REQUIRE(ring && ring->records && idx, PQLK_E_NULL);
   PQLK_REQUIRE(ring->obs_dim > 0 && ring->capacity > 0 && b >= 0, PQLK_E_SHAPE);
   RecLayout L = rec_layout(ring->obs_dim, ring->act_dim);
@@ -605,7 +593,7 @@ extern "C" int pqlk_replay_gather_fused(const PqlReplayDesc* ring, const int64_t
     const dim3 g((unsigned)fb), t(256);
 #define PQLK_GATHER_OBS(NORM, RR) \
     hipLaunchKernelGGL((k_replay_gather_obs<NORM, RR>), g, t, 0, pqlk_s(stream), ring->records, L, ring->capacity, idx, b, mean, var, eps, \
-                       clamp5, x_sa, ld_sa, xn_obs, ld_o, write_pads, lgp, nt_loads & 4)
+                       clamp5, x_sa, ld_sa, xn_obs, ld_o, write_pads, lgp)
 #define PQLK_GATHER_OBS_R(NORM) \
     do { if (R == 1) PQLK_GATHER_OBS(NORM, 1); else if (R == 2) PQLK_GATHER_OBS(NORM, 2); else PQLK_GATHER_OBS(NORM, 4); } while (0)
     if (mean) PQLK_GATHER_OBS_R(true); else PQLK_GATHER_OBS_R(false);

@@ -102,8 +102,6 @@ def run(name, quick=False, iters=30, auto=False):
                     print(f"  R={R} waves/CU={wpc} nopad={nopad} nt={nt}: b2b {us:6.2f} us ({alg / us / 1e6 / 8:.3f} of 8 TB/s)   "
                           f"iso {ui:6.2f} us ({alg / ui / 1e6 / 8:.3f})   moved {real / ui / 1e6:5.2f} TB/s iso", flush=True)
     print(f"  auto (learner flags 3): b2b {b2b(flags=3):6.2f} us   iso {iso(flags=3):6.2f} us ({alg / iso(flags=3) / 1e6 / 8:.3f})", flush=True)
-    print(f"  auto, fp32 division sequence (flags 3 | 16): b2b {b2b(flags=19):6.2f} us   iso {iso(flags=19):6.2f} us", flush=True)
-    print(f"  auto (again):           b2b {b2b(flags=3):6.2f} us   iso {iso(flags=3):6.2f} us", flush=True)
     print(f"  auto, no normalisation: b2b {b2b(False, 3):6.2f} us   iso {iso(False, 3):6.2f} us", flush=True)
 
 
