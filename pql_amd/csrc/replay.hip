@@ -435,27 +435,26 @@ __global__ __launch_bounds__(256) void k_replay_gather_obs(const float* __restri
   const int64_t rows_trip = (int64_t)R * G;
   const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
+  // Every index and record load below is UNCONDITIONAL straight-line code (rows past b re-read index b - 1, idle lanes re-read
+  // chunk 0 of their record: same cache line, nothing stored).  With the loads under `r < b` / `active` branches the compiler put a
+  // full `s_waitcnt vmcnt(0)` between the R record loads of a trip -- three dependent memory round trips where one was meant
+  // (tools/kernel_resources.py full_drains: 7 -> see the test).
+  const int clq = active ? cl : 0;
   int64_t nsrc[R];
 #pragma unroll
-  for (int i = 0; i < R; ++i) {
-    const int64_t r = wave * rows_trip + i * G + grp;
-    nsrc[i] = r < b ? idx[r] : 0;
-  }
+  for (int i = 0; i < R; ++i) nsrc[i] = idx[min(wave * rows_trip + i * G + grp, b - 1)];
   for (int64_t r0 = wave * rows_trip; r0 < b; r0 += nwaves * rows_trip) {
     float4 v[R];
     int64_t srcs[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) srcs[i] = nsrc[i];
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-      const int64_t rn = r0 + nwaves * rows_trip + i * G + grp;
-      nsrc[i] = rn < b ? idx[rn] : 0;
-    }
+    for (int i = 0; i < R; ++i) nsrc[i] = idx[min(r0 + nwaves * rows_trip + i * G + grp, b - 1)];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
       int64_t src = srcs[i];
-      if (src < 0 || src >= capacity) src = 0;   // never fault on a bad index
-      v[i] = active ? reinterpret_cast<const float4*>(records + src * L.ld)[cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+      src = (src < 0 || src >= capacity) ? 0 : src;   // never fault on a bad index
+      v[i] = reinterpret_cast<const float4*>(records + src * L.ld)[clq];
     }
 #pragma unroll
     for (int i = 0; i < R; ++i) {

@@ -535,3 +535,20 @@ def test_no_kernel_of_the_library_goes_through_scratch():
     assert not bad, {k: (v.get("vgpr_spill_count"), v.get("private_segment_fixed_size")) for k, v in bad.items()}
     for k, v in res.items():   # the register file is 512 per SIMD lane: nothing may ask for more than 256 + 256
         assert v.get("vgpr_count", 0) <= 512 and v.get("max_flat_workgroup_size", 0) <= 1024, k
+
+
+def test_gather_kernels_keep_their_counted_waits():
+    """The gather kernels are chains of loads and stores on gfx9's one in-order vector-memory counter; what they cost hangs on the
+    compiler waiting with COUNTED `s_waitcnt vmcnt(n)`.  Round 4 twice produced a kernel with the same bits and 14 full drains
+    (`vmcnt(0)`) instead of 2 -- 23 -> 28-30 us -- by adding a wave-uniform branch, then a template flag and selects, to the
+    per-record loop; no parity test can see that.  This counts the drains in the built library (tools/kernel_resources.py)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    if not os.path.exists(f"{kr.LLVM}/llvm-objdump"):
+        pytest.skip("no llvm-objdump")
+    drains = kr.full_drains(want=("k_replay_gather_fast<true", "k_replay_gather_obs<true"))
+    assert len(drains) == 7, sorted(drains)
+    for name, n in drains.items():
+        limit = 3 if "gather_fast" in name else 5
+        assert n <= limit, f"{name}: {n} full drains of the vector-memory queue (was 2 / 3-5): look at the loop's waits before shipping this"

@@ -55,6 +55,32 @@ def resources(lib=LIB):
     return out
 
 
+def full_drains(lib=LIB, want=()):
+    """-> {demangled kernel name: number of `s_waitcnt vmcnt(0)` instructions} for the kernels whose name contains one of `want`.
+    The gather kernels are latency-bound chains of loads and stores on gfx9's ONE in-order vector-memory counter: their speed hangs
+    on the compiler keeping counted waits.  Round 4: a wave-uniform branch added inside k_replay_gather_fast's per-record loop (and
+    later a template flag + selects in place of a branch) made the compiler drain the queue before every store -- 2 -> 14 full
+    drains, the same bits, 23 -> 28-30 us.  Parity tests cannot see that; this count can."""
+    out = {}
+    filt = shutil.which("c++filt")
+    with tempfile.TemporaryDirectory() as td:
+        so = os.path.join(td, "lib.so")
+        shutil.copy(lib, so)
+        subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", so], check=True, capture_output=True, cwd=td)
+        for f in sorted(os.listdir(td)):
+            if "amdgcn" not in f:
+                continue
+            asm = subprocess.run([f"{LLVM}/llvm-objdump", "-d", os.path.join(td, f)], check=True, capture_output=True, text=True).stdout
+            for m in re.finditer(r"^[0-9a-f]+ <([^>]+)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", asm, re.M | re.S):
+                name = m.group(1)
+                if filt:
+                    name = subprocess.run([filt, name], capture_output=True, text=True).stdout.strip() or name
+                name = re.sub(r"\(.*", "", name)
+                if any(w in name for w in want):
+                    out[name] = len(re.findall(r"s_waitcnt vmcnt\(0\)", m.group(2)))
+    return out
+
+
 def spilling(res):
     """Kernels that go through scratch memory: spilled VGPRs or a private segment.  (SGPRs spilled into VGPR lanes --
     `sgpr_spill_count` with no scratch -- cost a v_readlane each and are listed, not failed.)"""
