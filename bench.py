@@ -230,18 +230,25 @@ class Schedule:
                 (self.v if self.mode == "v_only" else self.p).learn_many(min(rr, remaining))
             return
         if k % self.r_env == 0:
+            # Issue order: each learner's hand-off is followed at once by its steps, the rollout of the NEXT slice goes last.  The
+            # data flow is the one of scripts/train_pql.py (the snapshots `update()` returns are copies taken at the hand-off, so
+            # it does not matter to P or to the rollout that V's steps are already queued behind it); what changes is that
+            # after the barrier + synchronise that opens a timed block the learners' queues do not sit idle while the host is
+            # still enqueuing the ~20 launches of the rollout (0.3 ms of a 17-ms block at --steps 20; nothing in steady state,
+            # where the host runs a slice ahead of the device).
+            nv = min(r, remaining)
+            rms = self.actor.obs_rms
             if self.pending is not None:
                 p_data, v_data = self.pending
-                rms = self.actor.obs_rms
                 self.critic, _, _ = self.v.update(self.policy, v_data, rms.get_states(self.v.device), 0)   # transitions + policy -> V
+            self.v.learn_many(nv)
+            if self.pending is not None:
                 self.policy, _, _ = self.p.update(self.critic, p_data, rms.get_states(self.p.device), 0)   # obs + critic -> P
+            self.p.learn_many(nv // self.r_p)
             self.actor.set_actor(self.policy)                                                               # policy -> rollout
             p_data, v_data, n = self.actor.explore_env(self.env, self.cfg.algo.horizon_len, random=False)
             self.global_steps += n
             self.pending = (p_data, v_data)
-            nv = min(r, remaining)
-            self.v.learn_many(nv)
-            self.p.learn_many(nv // self.r_p)
 
 
 def v_section(v):

@@ -222,10 +222,12 @@ class PQLPLearner:
                                                L.ptr(x_sa), ws["ld_sa"], None, L.ptr(x_obs), ws["ld_o"], None, None,
                                                L.stream(self.device)))
 
-    def _prefetch(self, ws):
-        """The next K steps' indices (torch's numbers, one launch) and ONE gather of their K x B observation rows."""
-        self._ahead.refill(self.cur_capacity)
-        self._gather(ws, self._ahead.idx, ws["K"] * ws["B"], ws["x_sa_all"], ws["x_obs_all"])
+    def _prefetch(self, ws, steps=None):
+        """The next K steps' indices (torch's numbers, one launch) and ONE gather of their K x B observation rows (`steps` < K: of
+        that many steps only, see PQLVLearner._prefetch)."""
+        Kp = ws["K"] if steps is None else max(1, min(ws["K"], int(steps)))
+        self._ahead.refill(self.cur_capacity, Kp)
+        self._gather(ws, self._ahead.idx, Kp * ws["B"], ws["x_sa_all"], ws["x_obs_all"])
         self._ahead_stamp = self._data_stamp()
 
     def _step_kernels(self, ws, idx, upto_backward=False, tiles=None):
@@ -390,6 +392,8 @@ class PQLPLearner:
                 self._run_graph.replay()
                 self.update_count += n
                 return self.sleep_time
+            if self._ahead is not None and self._ahead.valid == 0 and n < ws["K"] and self.cur_capacity < (1 << 28):
+                self._prefetch(ws, steps=n)   # a partial run: fetch what its n steps will use
         for _ in range(n):
             self.learn()
         return self.sleep_time

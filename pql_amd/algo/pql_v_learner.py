@@ -473,18 +473,20 @@ class PQLVLearner:
                                                L.ptr(x_sa), ws["ld_sa"], L.ptr(xn_sa), None if actor_in_sa else L.ptr(ws["xn_obs"]),
                                                ws["ld_o"], L.ptr(rew), L.ptr(done), L.stream(self.device)))
 
-    def _prefetch(self, ws):
+    def _prefetch(self, ws, steps=None):
         """Draws of the next K steps in one launch (torch's own numbers, pql_amd/utils/rng.py) and ONE gather of their K x B
         rows: the ring does not change between two `update()` calls, so what the reference samples at the start of each of
         those steps (simple_replay.py:85-104) can be fetched together -- 102 MB per launch at cfg #2 instead of eight
-        latency-bound 12.75-MB launches."""
+        latency-bound 12.75-MB launches.  `steps` < K (learn_many of a partial run): only that many steps' draws, rows and
+        target actions -- the rest would be dropped unused at the next `update()`."""
         K, B = ws["K"], ws["B"]
-        self._ahead.refill(self.memory.cur_capacity)
-        self._gather(ws, self._ahead.idx, K * B, ws["x_sa_all"], ws["xn_sa_all"], ws["rew_all"], ws["done_all"])
+        Kp = K if steps is None else max(1, min(K, int(steps)))
+        self._ahead.refill(self.memory.cur_capacity, Kp)
+        self._gather(ws, self._ahead.idx, Kp * B, ws["x_sa_all"], ws["xn_sa_all"], ws["rew_all"], ws["done_all"])
         if ws["actor_ahead"]:   # a' = clamp(tanh(actor(s')) + clamp(0.8 N(0,1), +-0.2), +-1) of all K steps -> action columns of their tiles
             algo, O = self.cfg.algo, self.memory.ring.O
-            xn = ws["xn_sa_all"].view(K * B, ws["ld_sa"])
-            mlp_forward_raw(self.actor.layout, self.actor.arena.data, xn, L.ACT_TANH_NOISE, self._ahead.normal.view(K * B, -1),
+            xn = ws["xn_sa_all"].view(K * B, ws["ld_sa"])[: Kp * B]
+            mlp_forward_raw(self.actor.layout, self.actor.arena.data, xn, L.ACT_TANH_NOISE, self._ahead.normal.view(K * B, -1)[: Kp * B],
                             algo.noise.tgt_pol_std, algo.noise.tgt_pol_noise_bound, ws["a_out_all"], xn[:, O:], packed=self.pk_actor, stash_all=2)
         self._ahead_stamp = self._data_stamp()
 
@@ -697,6 +699,8 @@ class PQLVLearner:
                 self._run_graph.replay()
                 self.update_count += n
                 return self.sleep_time
+            if self._ahead is not None and self._ahead.valid == 0 and n < ws["K"] and self.memory.cur_capacity < (1 << 28):
+                self._prefetch(ws, steps=n)   # a partial run: fetch what its n steps will use, not K steps' worth
         for _ in range(n):
             self.learn()
         return self.sleep_time

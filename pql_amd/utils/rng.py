@@ -86,7 +86,8 @@ def _verify(device):
 class DrawAhead:
     """The next `depth` steps' draws of ONE learner, produced by one launch and handed out step by step.
 
-    refill(range)   on the caller's current stream: draws for steps now .. now + depth - 1 at the generator's current offset
+    refill(range[, steps])  on the caller's current stream: draws for steps now .. now + depth - 1 (or the first `steps` of them)
+                    at the generator's current offset
     take()          slot of the next step; moves the generator past that step's draws (host only)
     invalidate()    drop what is left (the ring / its bound changed); the next refill starts at the generator's offset,
                     i.e. exactly where a sequence of torch calls would be
@@ -101,10 +102,13 @@ class DrawAhead:
         self.inc = philox_increment(n_idx) + philox_increment(n_nrm)
         self.pos, self.valid, self.base = 0, 0, 0
 
-    def refill(self, rng_range):
+    def refill(self, rng_range, steps=None):
+        """steps: draw only the first `steps` (<= depth) steps -- a caller that knows it will make fewer (the last, partial run of a
+        timed block).  Same numbers per step either way: a step's draws depend on the generator offset alone."""
+        n = self.depth if steps is None else max(1, min(self.depth, int(steps)))
         self.base = int(self.gen.get_offset())
-        launch_draws(self.gen.initial_seed(), self.base, rng_range, self.idx, self.normal, self.depth, self.contract, self.device)
-        self.pos, self.valid = 0, self.depth
+        launch_draws(self.gen.initial_seed(), self.base, rng_range, self.idx, self.normal, n, self.contract, self.device)
+        self.pos, self.valid = 0, n
 
     def take(self):
         slot = self.pos

@@ -416,11 +416,12 @@ def test_learn_many_replays_a_whole_run_as_one_graph_with_the_bits_of_the_per_st
                 else:
                     for _ in range(n):
                         v.learn()
-            if many:
-                p.learn_many(Kp)
-            else:
-                for _ in range(Kp):
-                    p.learn()
+            for n in ([Kp] if it != 2 else [1, Kp - 1]):   # (a partial run prefetches only its own steps' draws and rows)
+                if many:
+                    p.learn_many(n)
+                else:
+                    for _ in range(n):
+                        p.learn()
         torch.cuda.synchronize()
         assert v.update_count == 4 * Kv and p.update_count == 4 * Kp
         if many:
